@@ -1,0 +1,155 @@
+/*
+ * tnf.h -- C ABI of libtnf_hip.so: MI355X (gfx950) kernels for the torch_nf
+ * coupling-flow hot path (RealNVP / BatchNorm / Affine forward, inverse, log_prob).
+ *
+ * The reference (srbittner/torch_nf) is pure Python on PyTorch-CPU and has no
+ * FFI of its own; every entry point below therefore replaces a Python method of
+ * the reference, cited as file:line relative to the upstream repo root.  The
+ * binding a maintainer would add on the reference side is the ctypes stub shown
+ * in INTEGRATION.md (and shipped as torch_nf_amd/_lib.py).
+ *
+ * Conventions
+ *  - Plain C linkage, plain pointers and sizes; no torch types, no exceptions.
+ *  - All data pointers are DEVICE pointers on the current HIP device, owned by
+ *    the caller, contiguous row-major:
+ *        z, z_out   (M, N, D)      sample-major: one sample = D contiguous values
+ *        params     (M_p, >=|theta|) with `params_row_stride` elements per row,
+ *                   packed exactly like the reference packs them
+ *                   (bijectors.py:222-235, 281-287; density_estimator.py:379-402)
+ *        log_det    (M, N)
+ *    M = max(M_z, M_p); M_z and M_p must be equal or one of them 1 (broadcast,
+ *    as torch.matmul does at bijectors.py:237-238).
+ *  - `dtype`: TNF_F32 or TNF_F64 is the type of z / params / outputs.  BatchNorm
+ *    statistics are always float32 (bijectors.py:345-346).
+ *  - Kernels are enqueued asynchronously on `stream` (a hipStream_t passed as
+ *    void*; NULL = the default stream) and never synchronise.
+ *  - Return value: 0 on success, a negative TNF_E* code otherwise;
+ *    tnf_last_error() then returns a thread-local message.  Nothing is launched
+ *    when an argument check fails.
+ */
+#ifndef TNF_H
+#define TNF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNF_VERSION 100 /* 0.1.0 */
+
+enum { TNF_F32 = 0, TNF_F64 = 1 };
+
+enum {
+    TNF_OK = 0,
+    TNF_EINVAL = -1,       /* bad argument (shape, NULL pointer, unsupported combination) */
+    TNF_EUNSUPPORTED = -2, /* valid request that this build has no kernel for */
+    TNF_ELAUNCH = -3,      /* HIP reported an error at launch */
+    TNF_EWORKSPACE = -4    /* workspace too small */
+};
+
+/* log-det output modes of tnf_coupling */
+enum { TNF_LD_STORE = 0, TNF_LD_ADD = 1, TNF_LD_SUB = -1 };
+
+/* fusion granularity of the flow-level entry points */
+enum {
+    TNF_FUSE_AUTO = 0,  /* fastest available for the shape */
+    TNF_FUSE_LAYER = 1, /* one fused kernel per coupling layer (k = 2*S launches) */
+    TNF_FUSE_FLOW = 2   /* the whole flow in one kernel (k = 1) */
+};
+
+int tnf_version(void);
+const char* tnf_last_error(void);
+
+/* Testing hooks.  TNF_OPT_FORCE_GENERIC != 0 makes tnf_coupling skip the MFMA
+ * specialisations so the tests can compare both kernels on the same inputs. */
+enum { TNF_OPT_FORCE_GENERIC = 1 };
+int tnf_set_option(int32_t key, int32_t value);
+
+/* Number of packed parameters of one RealNVP layer / of the whole coupling flow.
+ * Replaces RealNVP.count_num_params (bijectors.py:244-262) and
+ * NormFlow.count_num_params (density_estimator.py:418-421) for arch_type
+ * "coupling".  Negative on invalid arguments. */
+int64_t tnf_coupling_num_params(int32_t D, int32_t num_layers, int32_t num_units,
+                                int32_t transform_upper);
+int64_t tnf_flow_num_params(int32_t D, int32_t num_stages, int32_t num_layers,
+                            int32_t num_units);
+
+/* Returns 1 if (D, L, U) has an MFMA fast-path kernel in this build, else 0. */
+int tnf_has_fast_path(int32_t D, int32_t num_layers, int32_t num_units);
+
+/* ---- bijector level -------------------------------------------------- */
+
+/* RealNVP.forward_and_log_det (bijectors.py:145-181) when inverse == 0,
+ * RealNVP.inverse_and_log_det (bijectors.py:183-206) when inverse != 0;
+ * the twin t/s MLP is RealNVP._t_s_layer (bijectors.py:208-242).
+ * log_det receives sum(s) (the FORWARD log-det in both directions) according
+ * to ld_mode.  The conditioner half of z is copied to z_out bit-identically.
+ * z_out must not alias z. */
+int tnf_coupling(int32_t dtype, const void* z, const void* params, void* z_out, void* log_det,
+                 int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_layers,
+                 int32_t num_units, int32_t transform_upper, int32_t inverse,
+                 int64_t params_row_stride, int32_t ld_mode, void* stream);
+
+/* Affine.forward_and_log_det (bijectors.py:277-295) / inverse_and_log_det
+ * (bijectors.py:297-315).  params = [alpha (D) | shift (D)].
+ * log_det (M_p, 1) receives sum(alpha). */
+int tnf_affine(int32_t dtype, const void* z, const void* params, void* z_out, void* log_det,
+               int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t inverse,
+               int64_t params_row_stride, void* stream);
+
+/* BatchNorm with cached statistics: inverse != 0 -> z*alpha + mean
+ * (bijectors.py:420-426); inverse == 0 -> (z - mean)/alpha, the use_last=True
+ * branch (bijectors.py:397-399).  log_det (1 element of `dtype`... always float32)
+ * receives -sum(log(alpha)).  rows = M*N. */
+int tnf_bn_apply(int32_t dtype, const void* z, const float* mean, const float* alpha, void* z_out,
+                 float* log_det, int64_t rows, int32_t D, int32_t inverse, void* stream);
+
+/* BatchNorm with batch statistics over all rows (use_last=False branch,
+ * bijectors.py:401-417), float32: z_out = (z - mu)/sqrt(var_biased + eps);
+ * mean_out / alpha_out (D) receive the statistics the reference caches
+ * (alpha = sqrt(var_unbiased(z)) / sqrt(var_unbiased(z_out)), mean = mean(z - z_out*alpha));
+ * log_det (1) = -sum(log(alpha)).  workspace: tnf_bn_batch_workspace_bytes(D) bytes. */
+int64_t tnf_bn_batch_workspace_bytes(int32_t D);
+int tnf_bn_batch_forward_f32(const float* z, float* z_out, float* mean_out, float* alpha_out,
+                             float* log_det, int64_t rows, int32_t D, float eps, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
+/* Base density of NormFlow.forward, float64 like the reference's numpy expression
+ * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as
+ * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)).  omega (rows, D) float64 -> out (rows) float64. */
+int tnf_base_log_density_f64(const double* omega, double* out, int64_t rows, int32_t D, void* stream);
+
+/* ---- flow level (arch_type "coupling", float32) ------------------------ */
+/* Stack per stage: RealNVP(upper), BN, RealNVP(lower), BN, Affine
+ * (density_estimator.py:260-270); bn_mean / bn_alpha are (2*S, D) float32 in
+ * forward order.  Workspace size for either entry point: */
+int64_t tnf_flow_workspace_bytes(int64_t M, int64_t N, int32_t D, int32_t num_stages, int32_t fusion);
+
+/* Returns 1 if the whole-flow kernel (TNF_FUSE_FLOW) exists for this configuration
+ * (MFMA fast path and all 2*S layers' operands fit the 160 KB of LDS), else 0. */
+int tnf_flow_fused_supported(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units);
+
+/* NormFlow.log_prob (density_estimator.py:408-416) = inverse_and_log_det
+ * (density_estimator.py:390-406) + base Gaussian.  Outputs, each optional (NULL):
+ *   log_prob (M,N), z0 (M,N,D) the base-space point, sum_log_det (M,N). */
+int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_mean,
+                          const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det,
+                          int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_stages,
+                          int32_t num_layers, int32_t num_units, int64_t params_row_stride,
+                          int32_t fusion, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The deterministic part of NormFlow.forward with freeze_bn=True
+ * (density_estimator.py:374-388): pushes base samples `omega` (M,N,D) through
+ * the stack.  Outputs: z_out (M,N,D); sum_log_det (M,N) = sum of the forward
+ * log-dets (the caller subtracts it from the base log-density, :387). */
+int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
+                         const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z,
+                         int64_t M_p, int64_t N, int32_t D, int32_t num_stages, int32_t num_layers,
+                         int32_t num_units, int64_t params_row_stride, int32_t fusion,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNF_H */

@@ -1,0 +1,339 @@
+"""Parity of the HIP path (through the C ABI) with the reference, on a real MI355X.
+
+Three kinds of evidence, all `-m gpu`:
+  1. the committed golden vectors (outputs of the reference itself, tests/golden/*.npz);
+  2. the CPU oracle on fresh seeded inputs at sizes it finishes in seconds;
+  3. size-independent properties at the benchmark size N = 2^20 (round trips,
+     forward/log_prob consistency, shard invariance, pass-through bit identity).
+
+Tolerances (float32): z and log-dets rtol 1e-5 / atol 2e-6 per layer (looser after an
+8-layer chain, stated where used); log_prob rtol 1e-5 -- the figure BASELINE.json's
+north_star states.  float64 cases: 1e-12.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+LOGP_RTOL = 1e-5  # north_star: "log_prob matching reference to rtol 1e-5"
+
+
+def T(a, dev="cuda"):
+    return torch.from_numpy(np.array(a)).to(dev)
+
+
+def tol(dtype):
+    return dict(rtol=1e-12, atol=1e-12) if dtype == torch.float64 else dict(rtol=1e-5, atol=2e-6)
+
+
+@pytest.fixture(scope="module")
+def tnf():
+    import torch_nf_amd
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch_nf_amd
+
+
+def _force_generic(tnf, on):
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FORCE_GENERIC, int(on)))
+
+
+# --------------------------------------------------------------------------
+# 1. golden vectors
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("generic", [False, True])
+def test_golden_coupling(tnf, generic):
+    g = load_golden("coupling")
+    _force_generic(tnf, generic)
+    try:
+        for ci, (D, L, U, upper, Mz, Mp, N, dt, extra) in enumerate(g["meta"].tolist()):
+            k = "c%02d_" % ci
+            z, p = T(g[k + "z"]), T(g[k + "params"])
+            layer = tnf.RealNVP(D, L, U, transform_upper=bool(upper))
+            assert p.shape[1] == layer.count_num_params() + extra  # trailing params are ignored
+            zf, ldf = layer.forward_and_log_det(z, p)
+            zi, ldi = layer.inverse_and_log_det(z, p)
+            torch.cuda.synchronize()
+            t = tol(z.dtype)
+            torch.testing.assert_close(zf.cpu(), T(g[k + "z_fwd"], "cpu"), **t)
+            torch.testing.assert_close(ldf.cpu(), T(g[k + "ld_fwd"], "cpu"), **t)
+            torch.testing.assert_close(zi.cpu(), T(g[k + "z_inv"], "cpu"), **t)
+            torch.testing.assert_close(ldi.cpu(), T(g[k + "ld_inv"], "cpu"), **t)
+            h = D // 2
+            sl = slice(0, h) if upper else slice(h, D)
+            assert torch.equal(zf[:, :, sl], z[:, :, sl].expand(zf.shape[0], -1, -1)), "pass-through half"
+            assert torch.equal(zi[:, :, sl], z[:, :, sl].expand(zf.shape[0], -1, -1)), "pass-through half"
+    finally:
+        _force_generic(tnf, False)
+
+
+def test_golden_affine_bn(tnf):
+    g = load_golden("affine_bn")
+    for ci, (D, Mz, Mp, N, dt, extra) in enumerate(g["affine_meta"].tolist()):
+        k = "a%02d_" % ci
+        z, p = T(g[k + "z"]), T(g[k + "params"])
+        layer = tnf.Affine(D)
+        zf, ldf = layer.forward_and_log_det(z, p)
+        zi, ldi = layer.inverse_and_log_det(z, p)
+        t = tol(z.dtype)
+        for got, name in ((zf, "z_fwd"), (ldf, "ld_fwd"), (zi, "z_inv"), (ldi, "ld_inv")):
+            torch.testing.assert_close(got.cpu(), T(g[k + name], "cpu"), **t)
+    for ci, (D, M, N) in enumerate(g["bn_meta"].tolist()):
+        k = "b%02d_" % ci
+        bn = tnf.BatchNorm(D)
+        zb, ldb = bn(T(g[k + "z"]))
+        torch.testing.assert_close(zb.cpu(), T(g[k + "z_batch"], "cpu"), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(bn.get_last_mean().cpu(), T(g[k + "mean"], "cpu"), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(bn.get_last_alpha().cpu(), T(g[k + "alpha"], "cpu"), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ldb.cpu(), T(g[k + "ld_batch"], "cpu"), rtol=1e-5, atol=1e-5)
+        assert ldb.dim() == 0
+        bn.set_last_stats(T(g[k + "mean"]), T(g[k + "alpha"]))
+        zf, ldf = bn(T(g[k + "z2"]), use_last=True)
+        zi, ldi = bn.inverse_and_log_det(T(g[k + "z2"]))
+        torch.testing.assert_close(zf.cpu(), T(g[k + "z_frozen"], "cpu"), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(zi.cpu(), T(g[k + "z_inv"], "cpu"), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(ldf.cpu(), T(g[k + "ld_frozen"], "cpu"), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(ldi.cpu(), T(g[k + "ld_inv"], "cpu"), rtol=1e-5, atol=1e-5)
+
+
+def _flow_from_golden(tnf, g, ci, conditioner=False):
+    D, S, L, U, N = g["meta"].tolist()[ci][:5]
+    nf = tnf.NormFlow(D, conditioner, "coupling", S, L, U)
+    return nf, D, S, L, U, N
+
+
+def _install_stats(nf, mean, alpha):
+    for b, m, a in zip(nf._bn_layers(), mean, alpha):
+        b.set_last_stats(T(m), T(a))
+
+
+@pytest.mark.parametrize("fusion", ["auto", "layer", "flow", "bijectors"])
+def test_golden_flow(tnf, fusion):
+    g = load_golden("flow")
+    L_ = tnf._lib
+    for ci in range(len(g["meta"])):
+        nf, D, S, L, U, N = _flow_from_golden(tnf, g, ci)
+        k = "f%02d_" % ci
+        fast = tnf.ops.has_fast_path(D, L, U)
+        if fusion in ("layer", "flow") and not fast:
+            continue
+        nf.params = T(g[k + "params"])
+        _install_stats(nf, g[k + "bn_mean"], g[k + "bn_alpha"])
+        nf.fusion = {"auto": L_.FUSE_AUTO, "layer": L_.FUSE_LAYER, "flow": L_.FUSE_FLOW,
+                     "bijectors": L_.FUSE_AUTO}[fusion]
+        if fusion == "bijectors":
+            nf._fused_ok = lambda z, p: False  # the reference's per-bijector loop, one kernel each
+        z_test = T(g[k + "z_test"])
+        with torch.no_grad():
+            lp = nf.log_prob(z_test)
+            z0, sld = nf.inverse_and_log_det(z_test, nf.params)
+            z_fz, lq_fz = nf._forward_from(g[k + "omega_fz"], nf.params, freeze_bn=True)
+        torch.testing.assert_close(lp.cpu(), T(g[k + "log_prob"], "cpu"), rtol=LOGP_RTOL, atol=1e-5)
+        torch.testing.assert_close(z0.cpu(), T(g[k + "z0"], "cpu"), rtol=2e-5, atol=1e-5)
+        torch.testing.assert_close(sld.cpu(), T(g[k + "sum_log_det"], "cpu"), rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(z_fz.cpu(), T(g[k + "z_fz"], "cpu"), rtol=2e-5, atol=1e-5)
+        assert lq_fz.dtype == torch.float64 and z_fz.dtype == torch.float32
+        torch.testing.assert_close(lq_fz.cpu(), T(g[k + "logq_fz"], "cpu"), rtol=LOGP_RTOL, atol=2e-5)
+
+
+def test_golden_flow_batch_stats_forward(tnf):
+    """forward with freeze_bn=False: batch statistics computed on the GPU, cached stats match."""
+    g = load_golden("flow")
+    for ci in range(len(g["meta"])):
+        nf, D, S, L, U, N = _flow_from_golden(tnf, g, ci)
+        k = "f%02d_" % ci
+        nf.params = T(g[k + "params"])
+        with torch.no_grad():
+            z, lq = nf._forward_from(g[k + "omega"], nf.params, freeze_bn=False)
+        torch.testing.assert_close(z.cpu(), T(g[k + "z_fwd"], "cpu"), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(lq.cpu(), T(g[k + "logq_fwd"], "cpu"), rtol=LOGP_RTOL, atol=1e-4)
+        for b, m, a in zip(nf._bn_layers(), g[k + "bn_mean"], g[k + "bn_alpha"]):
+            torch.testing.assert_close(b.get_last_mean().cpu(), T(m, "cpu"), rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(b.get_last_alpha().cpu(), T(a, "cpu"), rtol=1e-4, atol=1e-5)
+
+
+def test_golden_cde(tnf):
+    g = load_golden("cde")
+    for ci, row in enumerate(g["meta"].tolist()):
+        D, S, L, U, D_x, nh, M, N = row[:8]
+        hidden = row[8:8 + nh]
+        k = "d%02d_" % ci
+        nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+        cde = tnf.ConditionalDensityEstimator(nf, D_x, hidden)
+        _install_stats(nf, g[k + "bn_mean"], g[k + "bn_alpha"])
+        params = T(g[k + "params"])
+        with torch.no_grad():
+            lp = nf.log_prob(T(g[k + "z_test"]), params)
+        torch.testing.assert_close(lp.cpu(), T(g[k + "log_prob"], "cpu"), rtol=LOGP_RTOL, atol=1e-5)
+        sd = {n[len(k) + 3:]: T(g[n]) for n in g if n.startswith(k + "sd_")}
+        if sd:  # whole module: param_net (torch.nn on the GPU) -> flow kernels
+            cde.load_state_dict(sd)
+            with torch.no_grad():
+                lp2 = cde.log_prob(T(g[k + "z_test"]), T(g[k + "x"]))
+            torch.testing.assert_close(lp2.cpu(), T(g[k + "log_prob"], "cpu"), rtol=2e-5, atol=2e-5)
+
+
+# --------------------------------------------------------------------------
+# 2. oracle on fresh inputs
+# --------------------------------------------------------------------------
+def _rand_flow(tnf, D, S, L, U, seed, sigma=0.1, M=1):
+    rng = np.random.RandomState(seed)
+    nf = tnf.NormFlow(D, M > 1, "coupling", S, L, U)
+    params = torch.tensor(rng.normal(0.0, sigma, (M, nf.D_params))).float()
+    mean = rng.normal(0.0, 0.3, (2 * S, D)).astype(np.float32)
+    alpha = np.exp(rng.normal(0.0, 0.2, (2 * S, D))).astype(np.float32)
+    _install_stats(nf, mean, alpha)
+    if M == 1:
+        nf.params = params.cuda()  # conditioner=False flows use their own row
+    stats = [(torch.from_numpy(m), torch.from_numpy(a)) for m, a in zip(mean, alpha)]
+    return nf, params, stats
+
+
+@pytest.mark.parametrize("D,S,L,U,N", [(64, 4, 2, 15, 16384), (32, 4, 2, 15, 16384), (64, 1, 1, 16, 1000),
+                                       (32, 2, 3, 15, 4097), (64, 4, 2, 15, 31), (2, 1, 2, 15, 1024),
+                                       (6, 2, 2, 20, 513)])
+def test_oracle_log_prob(tnf, oracle, D, S, L, U, N):
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=N + D)
+    z = torch.randn(1, N, D, generator=torch.Generator().manual_seed(1))
+    want = oracle.flow_log_prob(z, params, D, S, L, U, stats)
+    for fusion in ([tnf._lib.FUSE_LAYER, tnf._lib.FUSE_FLOW] if tnf.ops.has_fast_path(D, L, U)
+                   else [tnf._lib.FUSE_AUTO]):
+        nf.fusion = fusion
+        with torch.no_grad():
+            got = nf.log_prob(z.cuda(), params.cuda())
+        torch.testing.assert_close(got.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
+
+
+def test_oracle_many_contexts(tnf, oracle):
+    """M_p = M_z > 1 (per-context weights, cfg 3 shape family) and M_p = 1 broadcast."""
+    D, S, L, U = 64, 4, 2, 15
+    for M, N in [(16, 512), (3, 40), (64, 1), (5, 17)]:
+        nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=M, M=M)
+        z = torch.randn(M, N, D, generator=torch.Generator().manual_seed(2))
+        want = oracle.flow_log_prob(z, params, D, S, L, U, stats)
+        for fusion in (tnf._lib.FUSE_LAYER, tnf._lib.FUSE_FLOW):
+            nf.fusion = fusion
+            with torch.no_grad():
+                got = nf.log_prob(z.cuda(), params.cuda())
+            torch.testing.assert_close(got.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
+        # one parameter row shared by all M sample batches
+        want1 = oracle.flow_log_prob(z, params[:1], D, S, L, U, stats)
+        with torch.no_grad():
+            got1 = nf.log_prob(z.cuda(), params[:1].cuda())
+        torch.testing.assert_close(got1.cpu(), want1, rtol=LOGP_RTOL, atol=1e-5)
+
+
+def test_config0_plumbing(tnf, oracle):
+    """BASELINE configs[0]: 2-D Gaussian, 2-layer RealNVP (1 stage), batch = 1024 contexts,
+    N = 1 (the LFI_gauss layout) -- the reference's own CPU-runnable case, here HIP vs oracle."""
+    D, S, L, U, M = 2, 1, 2, 15, 1024
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=7, M=M)
+    omega = np.random.RandomState(3).normal(0, 1, (M, 1, D))
+    z_want, lq_want, _ = oracle.flow_forward(omega, params, D, S, L, U, stats)
+    with torch.no_grad():
+        z, lq = nf._forward_from(omega, params.cuda(), freeze_bn=True)
+        lp = nf.log_prob(z, params.cuda())
+    torch.testing.assert_close(z.cpu(), z_want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lq.cpu(), lq_want, rtol=LOGP_RTOL, atol=1e-5)
+    torch.testing.assert_close(lp.cpu().double(), lq_want, rtol=1e-4, atol=1e-4)
+
+
+def test_host_tensors_are_staged(tnf, oracle):
+    """CPU tensors in -> computed on the GPU -> CPU tensors out (drop-in for CPU-only callers)."""
+    D, L, U = 8, 2, 15
+    layer = tnf.RealNVP(D, L, U)
+    rng = np.random.RandomState(0)
+    p = torch.tensor(rng.normal(0, 0.1, (3, layer.count_num_params())))
+    z = torch.tensor(rng.normal(0, 1, (3, 7, D)))
+    got, ld = layer(z, p)
+    want, ld_want = oracle.coupling(z, p, D, L, U, True, False)
+    assert got.device.type == "cpu" and got.dtype == torch.float64
+    torch.testing.assert_close(got, want, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(ld, ld_want, rtol=1e-12, atol=1e-12)
+
+
+# --------------------------------------------------------------------------
+# 3. properties at the benchmark size
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [64, 32])
+def test_full_size_properties(tnf, oracle, D):
+    S, L, U, N = 4, 2, 15, 1 << 20
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=11)
+    params = params.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    omega = torch.randn(1, N, D, device="cuda", generator=gen)
+    mean, alpha = nf._bn_stats(torch.device("cuda"))
+    ops, L_ = tnf.ops, tnf._lib
+    with torch.no_grad():
+        z, sld_f = ops.flow_forward_raw(omega, params, mean, alpha, D, S, L, U, L_.FUSE_FLOW)
+        z_l, sld_fl = ops.flow_forward_raw(omega, params, mean, alpha, D, S, L, U, L_.FUSE_LAYER)
+        lp, z0, sld_i = ops.flow_log_prob_raw(z, params, mean, alpha, D, S, L, U, L_.FUSE_FLOW,
+                                              want_z0=True, want_sld=True)
+        lp_l, z0_l, sld_il = ops.flow_log_prob_raw(z, params, mean, alpha, D, S, L, U, L_.FUSE_LAYER,
+                                                   want_z0=True, want_sld=True)
+    # whole-flow kernel == per-layer chain
+    torch.testing.assert_close(z, z_l, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lp, lp_l, rtol=LOGP_RTOL, atol=1e-5)
+    # inverse(forward(omega)) == omega, and the two log-det sums agree
+    torch.testing.assert_close(z0, omega, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(z0_l, omega, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(sld_i, sld_f, rtol=1e-4, atol=1e-4)
+    # log_prob(z) == log N(omega) - sum_log_det  (density_estimator.py:387 vs :413-416)
+    base = -0.5 * (omega.double() ** 2).sum(2) - D * np.log(np.sqrt(2 * np.pi))
+    torch.testing.assert_close(lp.double(), base - sld_f.double(), rtol=1e-4, atol=1e-3)
+    # shard invariance: evaluating a slice == slicing the evaluation (what multi-GPU relies on)
+    lo, hi = 123457, 654321
+    with torch.no_grad():
+        lp_s, _, _ = ops.flow_log_prob_raw(z[:, lo:hi].contiguous(), params, mean, alpha, D, S, L, U, L_.FUSE_FLOW)
+    assert torch.equal(lp_s, lp[:, lo:hi])
+    # a 2^16-sample slice against the CPU oracle (parity on the same run)
+    sl = slice(1 << 19, (1 << 19) + (1 << 16))
+    want = oracle.flow_log_prob(z[:, sl].cpu(), params.cpu(), D, S, L, U, stats)
+    torch.testing.assert_close(lp[:, sl].cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
+    assert torch.isfinite(lp).all()
+
+
+def test_full_size_layer_roundtrip(tnf):
+    """One RealNVP layer at N = 2^20: inverse(forward(z)) == z, log-dets equal, pass-through exact."""
+    D, L, U, N = 64, 2, 15, 1 << 20
+    layer = tnf.RealNVP(D, L, U, transform_upper=False)
+    rng = np.random.RandomState(5)
+    p = torch.tensor(rng.normal(0, 0.1, (1, layer.count_num_params()))).float().cuda()
+    z = torch.randn(1, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    with torch.no_grad():
+        zf, ldf = layer.forward_and_log_det(z, p)
+        zi, ldi = layer.inverse_and_log_det(zf, p)
+    assert torch.equal(zf[:, :, D // 2:], z[:, :, D // 2:])
+    torch.testing.assert_close(zi, z, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ldi, ldf, rtol=1e-5, atol=1e-6)
+
+
+def test_edge_shapes(tnf, oracle):
+    """Ragged / tiny inputs: N below one MFMA tile, N = 1, tails that are not a multiple of 16 or 32."""
+    D, S, L, U = 64, 4, 2, 15
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=21)
+    for N in (1, 2, 15, 16, 17, 33, 63, 257):
+        z = torch.randn(1, N, D, generator=torch.Generator().manual_seed(N))
+        want = oracle.flow_log_prob(z, params, D, S, L, U, stats)
+        for fusion in (tnf._lib.FUSE_LAYER, tnf._lib.FUSE_FLOW):
+            nf.fusion = fusion
+            with torch.no_grad():
+                got = nf.log_prob(z.cuda(), params.cuda())
+            torch.testing.assert_close(got.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
+    empty = torch.zeros(1, 0, D, device="cuda")
+    with torch.no_grad():
+        assert nf.log_prob(empty, params.cuda()).shape == (1, 0)
+
+
+def test_errors_are_loud(tnf):
+    layer = tnf.RealNVP(8, 2, 15)
+    z = torch.zeros(2, 4, 8, device="cuda")
+    with pytest.raises(tnf._lib.TnfError):  # parameter row too short
+        layer(z, torch.zeros(2, 10, device="cuda"))
+    with pytest.raises(RuntimeError):  # M_z = 2 vs M_p = 3 do not broadcast
+        layer(z, torch.zeros(3, layer.count_num_params(), device="cuda"))
+    with pytest.raises(TypeError):
+        layer(z.half(), torch.zeros(2, layer.count_num_params(), device="cuda").half())

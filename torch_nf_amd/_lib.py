@@ -1,0 +1,89 @@
+"""ctypes binding of libtnf_hip.so (the C ABI declared in include/tnf.h).
+
+This is the only place the package touches native code.  The library is built
+in-tree by `__graft_entry__.build()` / `make -C torch_nf_amd/csrc`; if it is
+missing the import fails loudly -- there is no CPU or PyTorch fallback for the
+flow arithmetic anywhere in this package.
+"""
+import ctypes
+import os
+
+import torch  # imported first so the HIP runtime torch ships is the one the library binds to
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtnf_hip.so")
+
+F32, F64 = 0, 1
+LD_STORE, LD_ADD, LD_SUB = 0, 1, -1
+FUSE_AUTO, FUSE_LAYER, FUSE_FLOW = 0, 1, 2
+OPT_FORCE_GENERIC = 1
+EUNSUPPORTED = -2
+
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); kept in step with include/tnf.h (tests/test_cabi.py checks it)
+SIGNATURES = {
+    "tnf_version": (ctypes.c_int, []),
+    "tnf_last_error": (ctypes.c_char_p, []),
+    "tnf_set_option": (ctypes.c_int, [_i32, _i32]),
+    "tnf_coupling_num_params": (_i64, [_i32, _i32, _i32, _i32]),
+    "tnf_flow_num_params": (_i64, [_i32, _i32, _i32, _i32]),
+    "tnf_has_fast_path": (ctypes.c_int, [_i32, _i32, _i32]),
+    "tnf_coupling": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32,
+                                    _i32, _i64, _i32, _vp]),
+    "tnf_affine": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp]),
+    "tnf_bn_apply": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "tnf_bn_batch_workspace_bytes": (_i64, [_i32]),
+    "tnf_bn_batch_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
+    "tnf_base_log_density_f64": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "tnf_flow_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32]),
+    "tnf_flow_fused_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "tnf_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
+                                             _i32, _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
+    "tnf_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                            _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "torch_nf_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C torch_nf_amd/csrc` (hipcc, --offload-arch=gfx950). "
+            "There is no non-HIP fallback." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library out of step
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class TnfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libtnf_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc):
+    if rc < 0:
+        raise TnfError(rc, lib.tnf_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def require_device():
+    """The product path is HIP only: fail loudly when no GPU is visible."""
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "torch_nf_amd needs a HIP device (MI355X / gfx950): torch.cuda.is_available() is False "
+            "and there is deliberately no CPU implementation of the flow kernels."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,226 @@
+"""Bijectors of the coupling-flow hot path, with the reference's Python interface.
+
+Drop-in for the hot-path classes of the reference's torch_nf/bijectors.py:
+  Bijector  (bijectors.py:7-71)    protocol: .name, .D, count_num_params(),
+                                   __call__ / forward_and_log_det / inverse_and_log_det
+  RealNVP   (bijectors.py:74-262)  coupling layer, twin t/s MLP from packed params
+  Affine    (bijectors.py:265-318) per-dimension exp(alpha)*z + shift
+  BatchNorm (bijectors.py:321-426) normalisation with log-det and cached statistics
+Same constructor arguments, validation (exact-type checks -> TypeError with the
+reference's message, range checks -> ValueError, clamps with a printed warning),
+return conventions ((z_out, log_det) with log_det (M,N) / (M,1) / 0-dim) and
+packed-parameter layout.  The arithmetic runs in the HIP kernels of
+libtnf_hip.so (include/tnf.h); nothing here computes on the CPU.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .error_formatters import format_type_err_msg
+
+
+class _Checked:
+    """Attribute with the reference's validation protocol: the value must be of
+    exactly `typ` (TypeError otherwise), then `rule(value)` either returns the
+    value to store (possibly clamped, after printing a warning) or raises ValueError."""
+
+    def __init__(self, label, typ, rule=None):
+        self.label, self.typ, self.rule = label, typ, rule
+
+    def __set_name__(self, owner, attr):
+        self.slot = "_checked_" + attr
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        return getattr(obj, self.slot)
+
+    def __set__(self, obj, val):
+        if type(val) is not self.typ:
+            raise TypeError(format_type_err_msg(obj, self.label, val, self.typ))
+        setattr(obj, self.slot, val if self.rule is None else self.rule(val))
+
+
+def _positive_dim(val):
+    if val < 1:
+        raise ValueError("Bijector dimensionality must be positive.")
+    return val
+
+
+class Bijector(object):
+    """Base class of the bijectors composed into normalizing flows (bijectors.py:7-71).
+
+    :param D: Dimensionality of the bijection.
+    :type D: int
+    """
+
+    D = _Checked("D", int, _positive_dim)
+
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+
+    def __call__(self, z, params):
+        return self.forward_and_log_det(z, params)
+
+    def forward_and_log_det(self, z, params):
+        """z (M, N, D), params (M, >=|theta|) -> (z', log|det J|)."""
+        raise NotImplementedError()
+
+    def inverse_and_log_det(self, z, params):
+        """Inverse map; returns the FORWARD log-det like the reference does."""
+        raise NotImplementedError()
+
+    def count_num_params(self):
+        return 0
+
+
+def _clamp_layers(val):
+    if val < 1:
+        raise ValueError("RealNVP.num_layers must be positive.")
+    if val > 5:
+        print("Warning: RealNVP.num_layers set to maximum of 5 (received %d)." % val)
+        return 5
+    return val
+
+
+def _clamp_units(val):
+    if val < 15:
+        print("Warning: num_units set to minimum of 15 (received %d)." % val)
+        return 15
+    if val > 1000:
+        print("Warning: num_units set to maximum of 1,000 (received %d)." % val)
+        return 1000
+    return val
+
+
+class RealNVP(Bijector):
+    """RealNVP coupling bijector (bijectors.py:74-262).
+
+    Two independent fully connected nets (shift t, log-scale s), both fed the
+    conditioner half z1, transform the other half: z2' = t + z2*exp(s).  With
+    transform_upper=True z1 = z[..., :D//2] and z2 = z[..., D//2:], otherwise the roles
+    swap.  One call = one fused HIP kernel (tnf_coupling): MLP, scale-shift, and the
+    wavefront-reduced log-det.
+
+    :param D: Dimensionality of the bijection.
+    :param num_layers: Number of hidden layers of each net (1..5, clamped).
+    :param num_units: Hidden width (15..1000, clamped).
+    :param transform_upper: transform the upper half conditioned on the lower half.
+    """
+
+    num_layers = _Checked("num_layers", int, _clamp_layers)
+    num_units = _Checked("num_units", int, _clamp_units)
+    transform_upper = _Checked("transform_upper", bool)
+
+    def __init__(self, D, num_layers, num_units, transform_upper=True):
+        super().__init__(D)
+        self.name = "RealNVP"
+        self.num_layers = num_layers
+        self.num_units = num_units
+        self.transform_upper = transform_upper
+
+    def _run(self, z, params, inverse):
+        return ops.coupling(z, params, self.D, self.num_layers, self.num_units,
+                            self.transform_upper, inverse)
+
+    def forward_and_log_det(self, z, params):
+        """bijectors.py:145-181: returns (cat(z1, t + z2*exp(s)), sum(s))."""
+        return self._run(z, params, False)
+
+    def inverse_and_log_det(self, z, params):
+        """bijectors.py:183-206: returns (cat(z1, (z2 - t)/exp(s)), sum(s))."""
+        return self._run(z, params, True)
+
+    def count_num_params(self):
+        """bijectors.py:244-262 (the C ABI exposes the same count as tnf_coupling_num_params)."""
+        h = self.D // 2
+        d_in = h + (self.D % 2) * (not self.transform_upper)
+        d_out = h + (self.D % 2) * self.transform_upper
+        U, L = self.num_units, self.num_layers
+        return int(2 * (d_in * U + d_out * U + d_out + U + (L - 1) * (U + 1) * U))
+
+
+class Affine(Bijector):
+    """Per-dimension scale and shift (bijectors.py:265-318); params = [alpha | shift]."""
+
+    def __init__(self, D):
+        super().__init__(D)
+        self.name = "Affine"
+
+    def forward_and_log_det(self, z, params):
+        """exp(alpha)*z + shift, log_det = sum(alpha) of shape (M, 1)."""
+        return ops.affine(z, params, self.D, False)
+
+    def inverse_and_log_det(self, z, params):
+        """(z - shift)/exp(alpha), same (forward) log_det."""
+        return ops.affine(z, params, self.D, True)
+
+    def count_num_params(self):
+        return 2 * self.D
+
+
+def _clamp_momentum(val):
+    if val < 0.0:
+        raise ValueError("BatchNorm.momentum cannot be negative.")
+    if val > 1.0:
+        print("Warning: BathNorm.momentum  set to maximum of 1.0 (received %.2E)." % val)
+        return 1.0
+    return val
+
+
+def _nonneg_eps(val):
+    if val < 0.0:
+        raise ValueError("BatchNorm.eps cannot be negative.")
+    return val
+
+
+class BatchNorm(Bijector):
+    """Batch-norm bijector that propagates its log-det and remembers the statistics
+    of its last batch-mode forward (bijectors.py:321-426).
+
+    forward(use_last=False): statistics over all M*N rows (HIP reduction in float64),
+        z_norm = (z - mu)/sqrt(var + eps); caches mean and alpha.
+    forward(use_last=True):  (z - last_mean)/last_alpha.
+    inverse:                 z*last_alpha + last_mean.
+    log_det = -sum(log(alpha)) (0-dim) in every case.
+
+    `momentum` is accepted and validated for interface parity; like in the reference
+    (which builds an nn.BatchNorm1d but never evaluates it in eval mode) running
+    averages never influence any output.
+    """
+
+    momentum = _Checked("momentum", float, _clamp_momentum)
+    eps = _Checked("eps", float, _nonneg_eps)
+
+    def __init__(self, D, momentum=0.1, eps=1e-5):
+        super().__init__(D)
+        self.name = "BatchNorm"
+        self.momentum = momentum
+        self.eps = eps
+        self._last_mean = torch.tensor(np.zeros(D)).float()
+        self._last_alpha = torch.tensor(np.ones(D)).float()
+
+    def get_last_mean(self):
+        return self._last_mean
+
+    def get_last_alpha(self):
+        return self._last_alpha
+
+    def set_last_stats(self, mean, alpha):
+        """Install cached statistics (e.g. restored from a checkpoint or all-reduced)."""
+        self._last_mean = mean.detach().float()
+        self._last_alpha = alpha.detach().float()
+
+    def __call__(self, z, use_last=False):
+        return self.forward_and_log_det(z, use_last=use_last)
+
+    def forward_and_log_det(self, z, use_last=False):
+        if use_last:
+            return ops.bn_apply(z, self._last_mean, self._last_alpha, False)
+        z_norm, log_det, mean, alpha = ops.bn_batch_forward(z, self.eps)
+        self._last_mean, self._last_alpha = mean, alpha
+        return z_norm, log_det
+
+    def inverse_and_log_det(self, z):
+        return ops.bn_apply(z, self._last_mean, self._last_alpha, True)

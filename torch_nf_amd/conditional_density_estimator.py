@@ -1,0 +1,100 @@
+"""ConditionalDensityEstimator with the reference's interface.
+
+Drop-in for torch_nf/conditional_density_estimator.py:10-104 of the reference: an
+nn.Module whose `param_net` (stock torch.nn Linear/Tanh[/Dropout] stack -- it runs on
+hipBLASLt when the module lives on the GPU and is NOT re-implemented here) maps a
+context x (M, D_x) to one flat flow-parameter row per context (M, D_params); sampling
+and density evaluation are delegated to the wrapped NormFlow, i.e. to the HIP kernels
+with per-context weights (M_p = M).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import density_estimator as de
+from .bijectors import _Checked
+
+
+def _pos_dx(val):
+    if val < 1:
+        raise ValueError("D_x %d must be greater than 0." % val)
+    return val
+
+
+def _pos_dparams(val):
+    if val < 1:
+        raise ValueError("D_params %d must be greater than 0." % val)
+    return val
+
+
+class ConditionalDensityEstimator(torch.nn.Module):
+    """:param density_estimator: a NormFlow built with conditioner=True (exact type, as in
+    the reference :48-49).  :param D_x: context width.  :param hidden_layers: list of
+    hidden widths of param_net.  :param dropout: add nn.Dropout after every activation."""
+
+    D_x = _Checked("D_x", int, _pos_dx)
+    D_params = _Checked("D_params", int, _pos_dparams)
+
+    def __init__(self, density_estimator, D_x, hidden_layers, dropout=False):
+        super().__init__()
+        self.density_estimator = density_estimator
+        self.D_x = D_x
+        self.D_params = density_estimator.D_params
+        self.hidden_layers = hidden_layers
+        self.dropout = dropout
+
+        # conditional_density_estimator.py:19-40 (module names are part of the state_dict)
+        widths = [D_x] + list(self.hidden_layers)
+        layers = []
+        for i in range(1, len(widths)):
+            layers.append(("linear%d" % i, torch.nn.Linear(widths[i - 1], widths[i])))
+            layers.append((("tanh%d" if i == 1 else "relu%d") % i, torch.nn.Tanh()))
+            if self.dropout:
+                layers.append(("dropout%d" % i, torch.nn.Dropout()))
+        layers.append(("linear%d" % len(widths), torch.nn.Linear(widths[-1], self.D_params)))
+        self.param_net = torch.nn.Sequential(OrderedDict(layers))
+        if density_estimator.device.type != "cpu":
+            self.param_net.to(density_estimator.device)
+
+    @property
+    def density_estimator(self):
+        return self.__dict__["_cde_flow"]
+
+    @density_estimator.setter
+    def density_estimator(self, val):
+        if type(val) not in [de.NormFlow]:
+            from .error_formatters import format_type_err_msg
+            raise TypeError(format_type_err_msg(self, "density_estimator", val, de.DensityEstimator))
+        self.__dict__["_cde_flow"] = val
+
+    @property
+    def hidden_layers(self):
+        return self.__dict__["_cde_hidden"]
+
+    @hidden_layers.setter
+    def hidden_layers(self, val):
+        from .error_formatters import format_type_err_msg
+        if type(val) is not list:
+            raise TypeError(format_type_err_msg(self, "hidden_layers", val, list))
+        for i, width in enumerate(val):
+            if type(width) is not int:
+                raise TypeError(format_type_err_msg(self, "hidden_layers[%d]" % i, val, int))
+            if width < 1:
+                raise ValueError("Hidden unit counts must be positive.")
+        self.__dict__["_cde_hidden"] = val
+
+    def _params_for(self, x):
+        weight = next(self.param_net.parameters())
+        if x.device != weight.device:
+            x = x.to(weight.device)
+        return self.param_net(x)
+
+    def __call__(self, x, N=100, freeze_bn=False):
+        """conditional_density_estimator.py:93-99: (z (M,N,D), log_q (M,N))."""
+        params = self._params_for(x)
+        return self.density_estimator(N=N, params=params, freeze_bn=freeze_bn)
+
+    def log_prob(self, z, x):
+        """conditional_density_estimator.py:101-104."""
+        params = self._params_for(x)
+        return self.density_estimator.log_prob(z, params)

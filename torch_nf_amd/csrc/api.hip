@@ -1,0 +1,311 @@
+// C-ABI entry points of libtnf_hip.so (declared in include/tnf.h): argument checks,
+// kernel selection and the launch sequences of the flow-level chains.
+#include <string.h>
+
+#include "tnf_common.h"
+
+namespace tnf {
+
+int g_force_generic = 0;
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(TNF_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return TNF_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int check_mnd(const char* fn, int64_t Mz, int64_t Mp, int64_t N, int D) {
+    if (Mz < 1 || Mp < 1 || N < 0) return fail(TNF_EINVAL, "%s: bad batch sizes M_z=%lld M_p=%lld N=%lld", fn, (long long)Mz, (long long)Mp, (long long)N);
+    if (Mz != Mp && Mz != 1 && Mp != 1)
+        return fail(TNF_EINVAL, "%s: M_z=%lld and M_p=%lld do not broadcast", fn, (long long)Mz, (long long)Mp);
+    if (D < 1) return fail(TNF_EINVAL, "%s: D=%d must be positive", fn, D);
+    return TNF_OK;
+}
+
+static int64_t round16(int64_t b) { return (b + 15) & ~(int64_t)15; }
+
+struct FlowWs {
+    int64_t fold, ldc, zbuf, ldbuf, total;
+};
+static FlowWs flow_ws(int64_t M, int64_t N, int D, int S) {
+    FlowWs w;
+    w.fold = 0;
+    w.ldc = round16(M * 2 * S * 2 * D * (int64_t)sizeof(float));
+    w.zbuf = w.ldc + round16(M * (int64_t)sizeof(float));
+    w.ldbuf = w.zbuf + round16(M * N * D * (int64_t)sizeof(float));
+    w.total = w.ldbuf + round16(M * N * (int64_t)sizeof(float));
+    return w;
+}
+
+}  // namespace tnf
+
+using namespace tnf;
+
+extern "C" {
+
+int tnf_version(void) { return TNF_VERSION; }
+
+const char* tnf_last_error(void) { return err_buf(); }
+
+int tnf_set_option(int32_t key, int32_t value) {
+    if (key == TNF_OPT_FORCE_GENERIC) {
+        g_force_generic = value;
+        return TNF_OK;
+    }
+    return fail(TNF_EINVAL, "tnf_set_option: unknown key %d", key);
+}
+
+int64_t tnf_coupling_num_params(int32_t D, int32_t L, int32_t U, int32_t upper) {
+    if (D < 1 || L < 1 || U < 1) return fail(TNF_EINVAL, "tnf_coupling_num_params: D=%d L=%d U=%d", D, L, U);
+    return coupling_num_params(D, L, U, upper);
+}
+
+int64_t tnf_flow_num_params(int32_t D, int32_t S, int32_t L, int32_t U) {
+    if (D < 1 || S < 1 || L < 1 || U < 1)
+        return fail(TNF_EINVAL, "tnf_flow_num_params: D=%d S=%d L=%d U=%d", D, S, L, U);
+    return flow_layout(D, S, L, U).total;
+}
+
+int tnf_has_fast_path(int32_t D, int32_t L, int32_t U) { return mfma_supported(D, L, U) ? 1 : 0; }
+
+int tnf_coupling(int32_t dtype, const void* z, const void* params, void* z_out, void* log_det,
+                 int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U,
+                 int32_t upper, int32_t inverse, int64_t pstride, int32_t ld_mode, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_coupling: dtype %d", dtype);
+    int rc = check_mnd("tnf_coupling", M_z, M_p, N, D);
+    if (rc) return rc;
+    if (D < 2) return fail(TNF_EINVAL, "tnf_coupling: D=%d needs both halves non-empty", D);
+    if (L < 1 || U < 1) return fail(TNF_EINVAL, "tnf_coupling: num_layers=%d num_units=%d", L, U);
+    if (ld_mode != TNF_LD_STORE && ld_mode != TNF_LD_ADD && ld_mode != TNF_LD_SUB)
+        return fail(TNF_EINVAL, "tnf_coupling: ld_mode %d", ld_mode);
+    if (pstride < coupling_num_params(D, L, U, upper))
+        return fail(TNF_EINVAL, "tnf_coupling: params row has %lld elements, layer needs %lld",
+                    (long long)pstride, (long long)coupling_num_params(D, L, U, upper));
+    if (!z || !params || !z_out || !log_det) return fail(TNF_EINVAL, "tnf_coupling: NULL pointer");
+    if (z == z_out) return fail(TNF_EINVAL, "tnf_coupling: z_out must not alias z");
+    if (N == 0) return TNF_OK;
+    hipStream_t st = as_stream(stream);
+    if (dtype == TNF_F32 && !g_force_generic && mfma_supported(D, L, U) && N >= 16 && aligned16(z) &&
+        aligned16(z_out)) {
+        MfmaLayerArgs a;
+        memset(&a, 0, sizeof(a));
+        a.z = (const float*)z;
+        a.z_out = (float*)z_out;
+        a.params = (const float*)params;
+        a.pstride = pstride;
+        a.ld_in = ld_mode == TNF_LD_STORE ? nullptr : (const float*)log_det;
+        a.ld_out = (float*)log_det;
+        a.ld_sign = ld_mode == TNF_LD_SUB ? -1.f : 1.f;
+        a.Mz = M_z; a.Mp = M_p; a.N = N;
+        a.D = D; a.L = L; a.U = U; a.upper = upper; a.inverse = inverse;
+        return launch_coupling_mfma(a, st);
+    }
+    return launch_coupling_generic(dtype, z, params, z_out, log_det, M_z, M_p, N, D, L, U, upper,
+                                   inverse, pstride, ld_mode, st);
+}
+
+int tnf_affine(int32_t dtype, const void* z, const void* params, void* z_out, void* log_det,
+               int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t inverse, int64_t pstride,
+               void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_affine: dtype %d", dtype);
+    int rc = check_mnd("tnf_affine", M_z, M_p, N, D);
+    if (rc) return rc;
+    if (pstride < 2 * (int64_t)D)
+        return fail(TNF_EINVAL, "tnf_affine: params row has %lld elements, needs %d", (long long)pstride, 2 * D);
+    if (!z || !params || !z_out || !log_det) return fail(TNF_EINVAL, "tnf_affine: NULL pointer");
+    return launch_affine(dtype, z, params, z_out, log_det, M_z, M_p, N, D, inverse, pstride,
+                         as_stream(stream));
+}
+
+int tnf_bn_apply(int32_t dtype, const void* z, const float* mean, const float* alpha, void* z_out,
+                 float* log_det, int64_t rows, int32_t D, int32_t inverse, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_bn_apply: dtype %d", dtype);
+    if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_bn_apply: rows=%lld D=%d", (long long)rows, D);
+    if (!z || !mean || !alpha || !z_out || !log_det) return fail(TNF_EINVAL, "tnf_bn_apply: NULL pointer");
+    return launch_bn_apply(dtype, z, mean, alpha, z_out, log_det, rows, D, inverse, as_stream(stream));
+}
+
+int64_t tnf_bn_batch_workspace_bytes(int32_t D) {
+    if (D < 1) return fail(TNF_EINVAL, "tnf_bn_batch_workspace_bytes: D=%d", D);
+    return round16(2 * (int64_t)D * (int64_t)sizeof(double) + (int64_t)D * (int64_t)sizeof(float));
+}
+
+int tnf_bn_batch_forward_f32(const float* z, float* z_out, float* mean_out, float* alpha_out,
+                             float* log_det, int64_t rows, int32_t D, float eps, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    if (rows < 2 || D < 1)
+        return fail(TNF_EINVAL, "tnf_bn_batch_forward_f32: rows=%lld (need > 1 value per feature) D=%d", (long long)rows, D);
+    if (!z || !z_out || !mean_out || !alpha_out || !log_det || !workspace)
+        return fail(TNF_EINVAL, "tnf_bn_batch_forward_f32: NULL pointer");
+    if (workspace_bytes < tnf_bn_batch_workspace_bytes(D))
+        return fail(TNF_EWORKSPACE, "tnf_bn_batch_forward_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)tnf_bn_batch_workspace_bytes(D));
+    return launch_bn_batch_forward(z, z_out, mean_out, alpha_out, log_det, rows, D, eps, workspace,
+                                   as_stream(stream));
+}
+
+int tnf_base_log_density_f64(const double* omega, double* out, int64_t rows, int32_t D, void* stream) {
+    if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_base_log_density_f64: rows=%lld D=%d", (long long)rows, D);
+    if (!omega || !out) return fail(TNF_EINVAL, "tnf_base_log_density_f64: NULL pointer");
+    return launch_base_log_density(omega, out, rows, D, as_stream(stream));
+}
+
+int tnf_flow_fused_supported(int32_t D, int32_t S, int32_t L, int32_t U) {
+    return flow_fused_supported(D, S, L, U) ? 1 : 0;
+}
+
+int64_t tnf_flow_workspace_bytes(int64_t M, int64_t N, int32_t D, int32_t S, int32_t fusion) {
+    if (M < 1 || N < 0 || D < 1 || S < 1)
+        return fail(TNF_EINVAL, "tnf_flow_workspace_bytes: M=%lld N=%lld D=%d S=%d", (long long)M, (long long)N, D, S);
+    const FlowWs w = flow_ws(M, N, D, S);
+    return fusion == TNF_FUSE_FLOW ? w.zbuf : w.total;  // the whole-flow kernel needs no z / log-det scratch
+}
+
+static int flow_common_checks(const char* fn, int64_t M_z, int64_t M_p, int64_t N, int D, int S,
+                              int L, int U, int64_t pstride, int fusion, const void* ws,
+                              int64_t ws_bytes, int* use_fused) {
+    int rc = check_mnd(fn, M_z, M_p, N, D);
+    if (rc) return rc;
+    if (S < 1 || L < 1 || U < 1) return fail(TNF_EINVAL, "%s: S=%d L=%d U=%d", fn, S, L, U);
+    if (pstride < flow_layout(D, S, L, U).total)
+        return fail(TNF_EINVAL, "%s: params row has %lld elements, flow needs %lld", fn,
+                    (long long)pstride, (long long)flow_layout(D, S, L, U).total);
+    if (!mfma_supported(D, L, U))
+        return fail(TNF_EUNSUPPORTED, "%s: no fused kernel for D=%d L=%d U=%d (compose bijector-level calls)", fn, D, L, U);
+    if (fusion == TNF_FUSE_AUTO) *use_fused = flow_fused_supported(D, S, L, U) ? 1 : 0;
+    else if (fusion == TNF_FUSE_FLOW) {
+        if (!flow_fused_supported(D, S, L, U))
+            return fail(TNF_EUNSUPPORTED, "%s: whole-flow kernel unavailable for D=%d S=%d L=%d U=%d", fn, D, S, L, U);
+        *use_fused = 1;
+    } else if (fusion == TNF_FUSE_LAYER) *use_fused = 0;
+    else return fail(TNF_EINVAL, "%s: fusion %d", fn, fusion);
+    const int64_t M = M_z > M_p ? M_z : M_p;
+    const FlowWs w = flow_ws(M, N, D, S);
+    const int64_t need = *use_fused ? w.zbuf : w.total;
+    if (!ws || ws_bytes < need)
+        return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)ws_bytes, (long long)need);
+    return TNF_OK;
+}
+
+int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_mean,
+                          const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det,
+                          int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L,
+                          int32_t U, int64_t pstride, int32_t fusion, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    int use_fused = 0;
+    int rc = flow_common_checks("tnf_flow_log_prob_f32", M_z, M_p, N, D, S, L, U, pstride, fusion,
+                                workspace, workspace_bytes, &use_fused);
+    if (rc) return rc;
+    if (!z || !params || !bn_mean || !bn_alpha) return fail(TNF_EINVAL, "tnf_flow_log_prob_f32: NULL pointer");
+    if (!log_prob && !z0 && !sum_log_det) return fail(TNF_EINVAL, "tnf_flow_log_prob_f32: no output requested");
+    if (!aligned16(z) || (z0 && !aligned16(z0)))
+        return fail(TNF_EINVAL, "tnf_flow_log_prob_f32: z / z0 must be 16-byte aligned");
+    if (z0 == z) return fail(TNF_EINVAL, "tnf_flow_log_prob_f32: z0 must not alias z");
+    if (N == 0) return TNF_OK;
+    hipStream_t st = as_stream(stream);
+    const int64_t M = M_z > M_p ? M_z : M_p;
+    const FlowWs w = flow_ws(M, N, D, S);
+    char* wsb = reinterpret_cast<char*>(workspace);
+    float* fold = reinterpret_cast<float*>(wsb + w.fold);
+    float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
+    rc = launch_flow_fold(params, bn_mean, bn_alpha, fold, ldc, M_p, D, S, L, U, pstride, 1, st);
+    if (rc) return rc;
+    if (use_fused)
+        return launch_flow_fused(z, params, fold, ldc, z0, sum_log_det, log_prob, M_z, M_p, N, D, S,
+                                 L, U, pstride, 1, st);
+    // one launch per coupling layer, last forward layer first
+    float* zbuf = z0 ? z0 : reinterpret_cast<float*>(wsb + w.zbuf);
+    float* ldbuf = sum_log_det ? sum_log_det : reinterpret_cast<float*>(wsb + w.ldbuf);
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const int nl = 2 * S;
+    for (int c = nl - 1; c >= 0; --c) {
+        MfmaLayerArgs a;
+        memset(&a, 0, sizeof(a));
+        const bool first = (c == nl - 1), last = (c == 0);
+        a.z = first ? z : zbuf;
+        a.z_out = (last && !z0) ? nullptr : zbuf;
+        a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+        a.pstride = pstride;
+        a.pre = fold + (int64_t)c * 2 * D;
+        a.fold_stride = (int64_t)nl * 2 * D;
+        a.ld_in = first ? nullptr : ldbuf;
+        a.ld_out = (last && !sum_log_det) ? nullptr : ldbuf;
+        a.ld_sign = 1.f;
+        a.ldc = ldc;
+        a.add_ldc = last ? 1 : 0;
+        a.log_prob = last ? log_prob : nullptr;
+        a.Mz = first ? M_z : M; a.Mp = M_p; a.N = N;
+        a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 1;
+        rc = launch_coupling_mfma(a, st);
+        if (rc) return rc;
+    }
+    return TNF_OK;
+}
+
+int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
+                         const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z,
+                         int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,
+                         int64_t pstride, int32_t fusion, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+    int use_fused = 0;
+    int rc = flow_common_checks("tnf_flow_forward_f32", M_z, M_p, N, D, S, L, U, pstride, fusion,
+                                workspace, workspace_bytes, &use_fused);
+    if (rc) return rc;
+    if (!omega || !params || !bn_mean || !bn_alpha || !z_out || !sum_log_det)
+        return fail(TNF_EINVAL, "tnf_flow_forward_f32: NULL pointer");
+    if (!aligned16(omega) || !aligned16(z_out))
+        return fail(TNF_EINVAL, "tnf_flow_forward_f32: omega / z_out must be 16-byte aligned");
+    if (z_out == omega) return fail(TNF_EINVAL, "tnf_flow_forward_f32: z_out must not alias omega");
+    if (N == 0) return TNF_OK;
+    hipStream_t st = as_stream(stream);
+    const int64_t M = M_z > M_p ? M_z : M_p;
+    const FlowWs w = flow_ws(M, N, D, S);
+    char* wsb = reinterpret_cast<char*>(workspace);
+    float* fold = reinterpret_cast<float*>(wsb + w.fold);
+    float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
+    rc = launch_flow_fold(params, bn_mean, bn_alpha, fold, ldc, M_p, D, S, L, U, pstride, 0, st);
+    if (rc) return rc;
+    if (use_fused)
+        return launch_flow_fused(omega, params, fold, ldc, z_out, sum_log_det, nullptr, M_z, M_p, N,
+                                 D, S, L, U, pstride, 0, st);
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const int nl = 2 * S;
+    for (int c = 0; c < nl; ++c) {
+        MfmaLayerArgs a;
+        memset(&a, 0, sizeof(a));
+        const bool first = (c == 0), last = (c == nl - 1);
+        a.z = first ? omega : z_out;
+        a.z_out = z_out;
+        a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+        a.pstride = pstride;
+        a.post = fold + (int64_t)c * 2 * D;
+        a.fold_stride = (int64_t)nl * 2 * D;
+        a.ld_in = first ? nullptr : sum_log_det;
+        a.ld_out = sum_log_det;
+        a.ld_sign = 1.f;
+        a.ldc = ldc;
+        a.add_ldc = last ? 1 : 0;
+        a.Mz = first ? M_z : M; a.Mp = M_p; a.N = N;
+        a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 0;
+        rc = launch_coupling_mfma(a, st);
+        if (rc) return rc;
+    }
+    return TNF_OK;
+}
+
+}  // extern "C"

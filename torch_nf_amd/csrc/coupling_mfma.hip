@@ -1,0 +1,268 @@
+// One fused kernel per RealNVP coupling layer (the k = 2S design): float32 MFMA twin
+// MLP + in-register scale-shift + wavefront-reduced log|det J|, with the adjacent
+// BatchNorm / Affine bijectors folded in as per-feature FMAs and, on the last layer
+// of a log_prob chain, the base Gaussian density.  HBM traffic per sample and launch:
+// read D floats + write D floats (+ 8 B of running log-det), i.e. 520 B at D = 64.
+#include "mfma_tile.h"
+#include "tnf_common.h"
+
+namespace tnf {
+
+// ---------------------------------------------------------------------------
+// Fold the parameter-only bijectors between coupling layers into one FMA per feature.
+// Forward order per stage (density_estimator.py:260-270): C_up, BN, C_low, BN, Affine.
+// inverse chain: layer c is preceded by  [Affine^-1 (c odd)] then BN^-1[c]:
+//      v -> ((v - shift)/e^a) * alpha + mu = v*(alpha/e^a) + (mu - shift*alpha/e^a)
+// forward chain: layer c is followed by BN[c] then [Affine (c odd)]:
+//      v -> ((v - mu)/alpha) * e^a + shift = v*(e^a/alpha) + (shift - mu*e^a/alpha)
+// ldc[m] = sum of all parameter-only log-dets: sum_s sum(a_s) - sum_c sum(log alpha_c)
+// (bijectors.py:293, 417).   fold layout: (Mp, 2S, 2, D) floats.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_mean,
+                 const float* __restrict__ bn_alpha, float* __restrict__ fold,
+                 float* __restrict__ ldc, int D, int S, int L, int U, int64_t pstride, int inverse) {
+    __shared__ float red[256];
+    const int m = blockIdx.x;
+    const float* p = params + (int64_t)m * pstride;
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    float acc = 0.f;
+    for (int idx = threadIdx.x; idx < 2 * S * D; idx += 256) {
+        const int c = idx / D, d = idx - c * D;
+        const int stage = c >> 1;
+        float A, B;
+        const float alpha = bn_alpha[c * D + d], mu = bn_mean[c * D + d];
+        acc -= logf(alpha);
+        float ea = 1.f, shift = 0.f;
+        if (c & 1) {
+            const float* ap = p + stage * fl.stage + fl.p_up + fl.p_low;
+            const float a = ap[d];
+            acc += a;
+            ea = expf(a);
+            shift = ap[D + d];
+        }
+        if (inverse) {
+            A = alpha / ea;
+            B = mu - shift * A;
+        } else {
+            A = ea / alpha;
+            B = shift - mu * A;
+        }
+        float* f = fold + (((int64_t)m * 2 * S + c) * 2) * D;
+        f[d] = A;
+        f[D + d] = B;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ldc[m] = red[0];
+}
+
+int launch_flow_fold(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
+                     float* ldc, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
+                     int inverse, hipStream_t st) {
+    hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
+                       bn_alpha, fold, ldc, D, S, L, U, pstride, inverse);
+    return check_launch("flow_fold");
+}
+
+// ---------------------------------------------------------------------------
+// The per-layer kernel.  256 threads = 4 waves; each wave keeps the layer's MFMA
+// operands in registers and walks 16-sample tiles grid-stride, with the next tile's
+// loads in flight during the current tile's arithmetic.
+// ---------------------------------------------------------------------------
+template <int H, int L, bool INV, int NT>
+__global__ void __launch_bounds__(256)
+coupling_mfma_kernel(MfmaLayerArgs a) {
+    constexpr int D = 2 * H;
+    constexpr int HT = (H + 15) / 16;
+    __shared__ __attribute__((aligned(16))) float cfold[4 * D];  // pre A|B, post A|B
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int64_t m = blockIdx.y;
+    const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
+
+    const bool has_pre = a.pre != nullptr, has_post = a.post != nullptr;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        cfold[i] = has_pre ? a.pre[mp * a.fold_stride + i] : 0.f;
+        cfold[2 * D + i] = has_post ? a.post[mp * a.fold_stride + i] : 0.f;
+    }
+
+    LayerW<H, L> w;
+    load_layer_w<H, L>(w, a.params + mp * a.pstride, a.U, lane);
+    const RegOperands<H, L> op{w};
+    __syncthreads();
+
+    const int c_off = a.upper ? 0 : H;
+    const int t_off = a.upper ? H : 0;
+    const float* zb = a.z + mz * a.N * D;
+    float* zo = a.z_out ? a.z_out + m * a.N * D : nullptr;
+    const float* ldi = a.ld_in ? a.ld_in + m * a.N : nullptr;
+    float* ldo = a.ld_out ? a.ld_out + m * a.N : nullptr;
+    float* lpo = a.log_prob ? a.log_prob + m * a.N : nullptr;
+    const float ldc = a.ldc ? a.ldc[mp] : 0.f;
+
+    // a "group" = NT consecutive 16-sample tiles handled by one wave per iteration
+    const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
+    const int64_t gstride = (int64_t)gridDim.x * 4;
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    if (grp >= ngroups) return;
+
+    f4 nx[NT][HT], ny[NT][HT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t row = (grp * NT + t) * 16 + s;
+        if (row >= a.N) row = a.N - 1;
+        const float* zr = zb + row * D + 4 * q;
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            nx[t][mm] = *reinterpret_cast<const f4*>(zr + c_off + 16 * mm);
+            ny[t][mm] = *reinterpret_cast<const f4*>(zr + t_off + 16 * mm);
+        }
+    }
+
+    for (; grp < ngroups; grp += gstride) {
+        f4 x[NT][HT], y[NT][HT];
+        float ld_prev[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                x[t][mm] = nx[t][mm];
+                y[t][mm] = ny[t][mm];
+            }
+            const int64_t row = (grp * NT + t) * 16 + s;
+            ld_prev[t] = (ldi && q == 0 && row < a.N) ? ldi[row] : 0.f;
+        }
+        // next group's loads stay in flight during this group's arithmetic
+        if (grp + gstride < ngroups) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int64_t nrow = ((grp + gstride) * NT + t) * 16 + s;
+                if (nrow >= a.N) nrow = a.N - 1;
+                const float* zr = zb + nrow * D + 4 * q;
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm) {
+                    nx[t][mm] = *reinterpret_cast<const f4*>(zr + c_off + 16 * mm);
+                    ny[t][mm] = *reinterpret_cast<const f4*>(zr + t_off + 16 * mm);
+                }
+            }
+        }
+        if (has_pre) {
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                const f4 ax = *reinterpret_cast<const f4*>(&cfold[c_off + 16 * mm + 4 * q]);
+                const f4 bx = *reinterpret_cast<const f4*>(&cfold[D + c_off + 16 * mm + 4 * q]);
+                const f4 ay = *reinterpret_cast<const f4*>(&cfold[t_off + 16 * mm + 4 * q]);
+                const f4 by = *reinterpret_cast<const f4*>(&cfold[D + t_off + 16 * mm + 4 * q]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        x[t][mm][j] = __builtin_fmaf(x[t][mm][j], ax[j], bx[j]);
+                        y[t][mm][j] = __builtin_fmaf(y[t][mm][j], ay[j], by[j]);
+                    }
+            }
+        }
+        float ssum[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ssum[t] = 0.f;
+        coupling_tile<H, L, INV, NT>(op, x, y, ssum);
+        if (has_post) {
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                const f4 ax = *reinterpret_cast<const f4*>(&cfold[2 * D + c_off + 16 * mm + 4 * q]);
+                const f4 bx = *reinterpret_cast<const f4*>(&cfold[3 * D + c_off + 16 * mm + 4 * q]);
+                const f4 ay = *reinterpret_cast<const f4*>(&cfold[2 * D + t_off + 16 * mm + 4 * q]);
+                const f4 by = *reinterpret_cast<const f4*>(&cfold[3 * D + t_off + 16 * mm + 4 * q]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        x[t][mm][j] = __builtin_fmaf(x[t][mm][j], ax[j], bx[j]);
+                        y[t][mm][j] = __builtin_fmaf(y[t][mm][j], ay[j], by[j]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t row = (grp * NT + t) * 16 + s;
+            const bool row_ok = row < a.N;
+            const float sred = reduce_q(ssum[t]);
+            float ld_tot = __builtin_fmaf(a.ld_sign, sred, ld_prev[t]);
+            if (a.add_ldc) ld_tot += ldc;
+            if (lpo) {
+                float sq = 0.f;
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sq = __builtin_fmaf(x[t][mm][j], x[t][mm][j], sq);
+                        sq = __builtin_fmaf(y[t][mm][j], y[t][mm][j], sq);
+                    }
+                sq = reduce_q(sq);
+                // density_estimator.py:413-416
+                if (q == 0 && row_ok)
+                    lpo[row] = -0.5f * sq - (float)D * 0.91893853320467274178f - ld_tot;
+            }
+            if (ldo && q == 0 && row_ok) ldo[row] = ld_tot;
+            if (zo && row_ok) {
+                float* zr = zo + row * D + 4 * q;
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm) {
+                    *reinterpret_cast<f4*>(zr + c_off + 16 * mm) = x[t][mm];
+                    *reinterpret_cast<f4*>(zr + t_off + 16 * mm) = y[t][mm];
+                }
+            }
+        }
+    }
+}
+
+bool mfma_supported(int D, int L, int U) {
+    if (D != 32 && D != 64) return false;
+    if (L < 1 || L > 3) return false;
+    return U >= 1 && U <= 16;
+}
+
+constexpr int kLayerNT = 2;  // 16-sample tiles per wave iteration
+
+template <int H, int L>
+static void launch_hl(const MfmaLayerArgs& a, dim3 grid, hipStream_t st) {
+    if (a.inverse)
+        hipLaunchKernelGGL((coupling_mfma_kernel<H, L, true, kLayerNT>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((coupling_mfma_kernel<H, L, false, kLayerNT>), grid, dim3(256), 0, st, a);
+}
+
+template <int H>
+static void launch_h(const MfmaLayerArgs& a, dim3 grid, hipStream_t st) {
+    switch (a.L) {
+        case 1: launch_hl<H, 1>(a, grid, st); break;
+        case 2: launch_hl<H, 2>(a, grid, st); break;
+        default: launch_hl<H, 3>(a, grid, st); break;
+    }
+}
+
+int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st) {
+    if (!mfma_supported(a.D, a.L, a.U))
+        return fail(TNF_EUNSUPPORTED, "coupling_mfma: no kernel for D=%d L=%d U=%d", a.D, a.L, a.U);
+    const int64_t M = a.Mz > a.Mp ? a.Mz : a.Mp;
+    if (M > 65535) return fail(TNF_EUNSUPPORTED, "coupling_mfma: M=%lld too large", (long long)M);
+    if (a.N <= 0) return TNF_OK;
+    const int64_t ngroups = (a.N + 16 * kLayerNT - 1) / (16 * kLayerNT);
+    int64_t bx = (ngroups + 3) / 4;
+    int64_t cap = 2048 / M;
+    if (cap < 1) cap = 1;
+    if (bx > cap) bx = cap;
+    dim3 grid((unsigned)bx, (unsigned)M);
+    if (a.D == 64) launch_h<32>(a, grid, st);
+    else launch_h<16>(a, grid, st);
+    return check_launch("coupling_mfma");
+}
+
+}  // namespace tnf

@@ -1,0 +1,106 @@
+// Shared host/device helpers for libtnf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tnf.h"
+
+namespace tnf {
+
+// ---- error reporting (thread-local message behind tnf_last_error) ---------
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- packed parameter layout of one RealNVP layer (bijectors.py:222-242) ---
+// [W_t (d_in*d_out, row-major [in][out]) | W_s | b_t (d_out) | b_s (d_out)] per MLP layer,
+// layers: d_in0 -> U, (U -> U) x (L-1), U -> d_out.
+struct CouplingDims {
+    int d_in, d_out;
+};
+__host__ __device__ inline CouplingDims coupling_dims(int D, int upper) {
+    CouplingDims c;
+    c.d_in = D / 2;
+    c.d_out = D / 2;
+    if (D & 1) {
+        c.d_in += upper ? 0 : 1;
+        c.d_out += upper ? 1 : 0;
+    }
+    return c;
+}
+__host__ __device__ inline int64_t coupling_num_params(int D, int L, int U, int upper) {
+    CouplingDims c = coupling_dims(D, upper);
+    return 2 * ((int64_t)c.d_in * U + (int64_t)c.d_out * U + c.d_out + U +
+                (int64_t)(L - 1) * (U + 1) * U);
+}
+// Offsets inside a parameter row of NormFlow(arch_type="coupling")
+// (density_estimator.py:260-270, 379-384): per stage [RealNVP(up) | RealNVP(low) | Affine(2D)].
+struct FlowLayout {
+    int64_t p_up, p_low, stage, total;
+};
+__host__ __device__ inline FlowLayout flow_layout(int D, int S, int L, int U) {
+    FlowLayout f;
+    f.p_up = coupling_num_params(D, L, U, 1);
+    f.p_low = coupling_num_params(D, L, U, 0);
+    f.stage = f.p_up + f.p_low + 2 * (int64_t)D;
+    f.total = f.stage * S;
+    return f;
+}
+
+// ---- runtime options (testing hooks) ---------------------------------------
+extern int g_force_generic;
+
+// ---- kernels implemented in the .hip files ----------------------------------
+int launch_coupling_generic(int dtype, const void* z, const void* params, void* z_out,
+                            void* log_det, int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U,
+                            int upper, int inverse, int64_t pstride, int ld_mode, hipStream_t st);
+
+bool mfma_supported(int D, int L, int U);
+// Fast per-layer kernel.  pre/post: folded per-feature constants [A(D)|B(D)] per m (stride
+// fold_stride floats) or NULL.  ld_in may be NULL (=0).  ld_out = ld_in + ld_sign*sum(s).
+// If log_prob != NULL the kernel finalises: log_prob = -0.5*|z'|^2 - D*log(sqrt(2pi)) - (ld + ldc[m]).
+struct MfmaLayerArgs {
+    const float* z;
+    float* z_out;  // may be NULL when finalising
+    const float* params;
+    int64_t pstride;
+    const float* pre;
+    const float* post;
+    int64_t fold_stride;
+    const float* ld_in;
+    float* ld_out;  // may be NULL
+    float ld_sign;
+    const float* ldc;  // per-m log-det constant, added when writing ld_out_total / log_prob
+    float* log_prob;
+    int add_ldc;  // add ldc[m] into ld_out as well
+    int64_t Mz, Mp, N;
+    int D, L, U, upper, inverse;
+};
+int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st);
+
+// fold BN/Affine constants for the flow-level chains. fold: (Mp, 2S, 2, D), ldc: (Mp)
+int launch_flow_fold(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
+                     float* ldc, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
+                     int inverse, hipStream_t st);
+
+int launch_flow_fused(const float* z, const float* params, const float* fold, const float* ldc,
+                      float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
+                      int64_t N, int D, int S, int L, int U, int64_t pstride, int inverse,
+                      hipStream_t st);
+bool flow_fused_supported(int D, int S, int L, int U);
+
+int launch_affine(int dtype, const void* z, const void* params, void* z_out, void* log_det,
+                  int64_t Mz, int64_t Mp, int64_t N, int D, int inverse, int64_t pstride,
+                  hipStream_t st);
+int launch_bn_apply(int dtype, const void* z, const float* mean, const float* alpha, void* z_out,
+                    float* log_det, int64_t rows, int D, int inverse, hipStream_t st);
+int launch_bn_batch_forward(const float* z, float* z_out, float* mean_out, float* alpha_out,
+                            float* log_det, int64_t rows, int D, float eps, void* ws, hipStream_t st);
+
+int launch_base_log_density(const double* omega, double* out, int64_t rows, int D, hipStream_t st);
+
+}  // namespace tnf

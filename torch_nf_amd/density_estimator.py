@@ -1,0 +1,267 @@
+"""NormFlow with the reference's interface, executing on MI355X.
+
+Drop-in for DensityEstimator / NormFlow of the reference's
+torch_nf/density_estimator.py (:11-55, :240-421): same constructor, validation,
+bijector stack, flat-parameter slicing, `__call__(N, params, freeze_bn)`,
+`forward`, `inverse_and_log_det`, `log_prob`, `count_num_params`, `D_params`,
+`params`, `bijectors`.
+
+Execution:
+  * arch_type="coupling", float32, no autograd, a shape with an MFMA kernel
+    (tnf_has_fast_path): ONE call of tnf_flow_log_prob_f32 / tnf_flow_forward_f32
+    (whole flow in one kernel, or one kernel per coupling layer).
+  * anything else: the reference's bijector loop, each bijector one HIP kernel.
+In scope are arch_type "coupling" and "affine"; "AR" (MAF) and the support layers
+are outside this hot path and raise NotImplementedError.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .bijectors import Affine, BatchNorm, Bijector, RealNVP, _Checked
+
+
+def _min_two(val):
+    if val < 2:
+        raise ValueError("DensityEstimator D %d must be greater than 1." % val)
+    return val
+
+
+class DensityEstimator(object):
+    """Abstract base (density_estimator.py:11-55)."""
+
+    D = _Checked("D", int, _min_two)
+    conditioner = _Checked("conditioner", bool)
+
+    def __init__(self, D, conditioner=False):
+        super().__init__()
+        self.D = D
+        self.conditioner = conditioner
+
+    def __call__(self, N=100, params=None):
+        if not self.conditioner:
+            return self.forward(self.params, N)
+        return self.forward(params, N)
+
+    def forward(self, params, N=100, freeze_bn=False):
+        raise NotImplementedError()
+
+    def log_prob(self, z, params=None):
+        raise NotImplementedError()
+
+    def count_num_params(self):
+        raise NotImplementedError()
+
+    def _param_init(self):
+        raise NotImplementedError()
+
+
+def _arch(val):
+    if val not in ("coupling", "AR", "affine"):
+        raise ValueError('NormalizingFlow arch_type must be "coupling", "AR", or "affine".')
+    return val
+
+
+def _stages(val):
+    if val < 1:
+        raise ValueError("NormalizingFlow num_stages %d must be greater than 0." % val)
+    return val
+
+
+def _layers(val):
+    if val < 1:
+        raise ValueError("NormalizingFlow num_layers arg %d must be greater than 0." % val)
+    return val
+
+
+def _units(val):
+    if val < 1:
+        raise ValueError("NormalizingFlow num_units %d must be greater than 0." % val)
+    if val < 15:
+        print("Warning: NormFlow.num_layers set to minimum of 15 (received %d)." % val)
+        return 15
+    return val
+
+
+class NormFlow(DensityEstimator):
+    """Normalizing flow q(z) = N(omega; 0, I) pushed through a bijector stack
+    (density_estimator.py:240-421).
+
+    arch_type="coupling": num_stages x [RealNVP(upper), BatchNorm, RealNVP(lower),
+    BatchNorm, Affine] (:260-270).  All bijector parameters live in one flat row
+    `params` (1, D_params) -- or are supplied per context as (M, D_params) when
+    conditioner=True -- and are consumed front-to-back by `forward` (:379-384) and
+    back-to-front by `inverse_and_log_det` (:399-402).
+
+    Extra (not in the reference): `device` -- where the flow's own `params` live
+    (default: the current HIP device when there is one).
+    """
+
+    arch_type = _Checked("arch_type", str, _arch)
+    num_stages = _Checked("num_stages", int, _stages)
+    num_layers = _Checked("num_layers", int, _layers)
+    num_units = _Checked("num_units", int, _units)
+
+    def __init__(self, D, conditioner=False, arch_type="AR", num_stages=1, num_layers=2,
+                 num_units=15, support_layer=None, device=None):
+        super().__init__(D, conditioner)
+        self.arch_type = arch_type
+        self.num_stages = num_stages
+        self.num_layers = num_layers
+        self.num_units = num_units
+        self.support_layer = support_layer
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+                else torch.device("cpu")
+        self.device = torch.device(device)
+        self.fusion = _lib.FUSE_AUTO
+
+        self.bijectors = []
+        if self.arch_type == "coupling":
+            for _ in range(self.num_stages):
+                self.bijectors.append(RealNVP(D, self.num_layers, self.num_units, transform_upper=True))
+                self.bijectors.append(BatchNorm(D))
+                self.bijectors.append(RealNVP(D, self.num_layers, self.num_units, transform_upper=False))
+                self.bijectors.append(BatchNorm(D))
+                self.bijectors.append(Affine(D))
+        elif self.arch_type == "AR":
+            raise NotImplementedError(
+                'NormFlow arch_type "AR" (MAF) is outside the MI355X hot path of this build; '
+                'use arch_type="coupling" or "affine".')
+        else:
+            self.bijectors.append(Affine(D))
+
+        if support_layer is not None:
+            if issubclass(type(support_layer), Bijector):
+                raise NotImplementedError(
+                    "support layers (ToInterval / ToSimplex) are outside the MI355X hot path of this build.")
+            raise TypeError("Support layer not Bijector.")
+
+        self.count_num_params()
+        if not self.conditioner:
+            self._param_init()
+
+    # -- parameters ---------------------------------------------------------
+    def count_num_params(self):
+        """density_estimator.py:418-421."""
+        self.D_params = 0
+        for bijector in self.bijectors:
+            self.D_params += bijector.count_num_params()
+
+    def _param_init(self):
+        """xavier_normal_ on a (1, D_params) row (density_estimator.py:352-356); drawn on the
+        host so torch.manual_seed reproduces the reference's initialisation, then moved."""
+        init = torch.nn.init.xavier_normal_(torch.zeros(1, self.D_params))
+        self.params = init.to(self.device).requires_grad_(True)
+        return None
+
+    # -- helpers ------------------------------------------------------------
+    def _bn_layers(self):
+        return [b for b in self.bijectors if b.name == "BatchNorm"]
+
+    def _bn_stats(self, dev):
+        bns = self._bn_layers()
+        mean = torch.stack([b.get_last_mean().detach().float().to(dev) for b in bns])
+        alpha = torch.stack([b.get_last_alpha().detach().float().to(dev) for b in bns])
+        return mean, alpha
+
+    def _fused_ok(self, z, params):
+        """One-call fused path: coupling stack, float32, no autograd, MFMA-covered shape."""
+        if self.arch_type != "coupling":
+            return False
+        if z.dtype != torch.float32 or params.dtype != torch.float32:
+            return False
+        if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
+            return False
+        return ops.has_fast_path(self.D, self.num_layers, self.num_units)
+
+    # -- sampling -----------------------------------------------------------
+    def __call__(self, N=100, params=None, freeze_bn=False):
+        if not self.conditioner:
+            return self.forward(self.params, N, freeze_bn=freeze_bn)
+        return self.forward(params, N, freeze_bn=freeze_bn)
+
+    def forward(self, params, N=100, freeze_bn=False):
+        """Draw N samples per parameter row and their log-density
+        (density_estimator.py:364-388).  The base draw is host numpy float64 exactly like
+        the reference (so np.random.seed reproduces it); returns z float32 and log_q
+        float64 on the parameters' device."""
+        M = params.size(0)
+        omega = np.random.normal(0.0, 1.0, (M, N, self.D))
+        return self._forward_from(omega, params, freeze_bn)
+
+    def _forward_from(self, omega, params, freeze_bn=False):
+        """`forward` with the base draw injected (numpy float64 (M,N,D))."""
+        home = params.device
+        dev = _lib.require_device()
+        omega64 = torch.as_tensor(np.ascontiguousarray(omega), dtype=torch.float64).to(dev)
+        z = omega64.float()
+        log_q = ops.base_log_density_f64(omega64)
+        p_dev = params if params.device == dev else params.to(dev)
+
+        if freeze_bn and self._fused_ok(z, p_dev):
+            mean, alpha = self._bn_stats(dev)
+            z, sld = ops.flow_forward_raw(z, p_dev, mean, alpha, self.D, self.num_stages,
+                                          self.num_layers, self.num_units, self.fusion)
+            log_q = log_q - sld
+        else:
+            idx = 0
+            for bijector in self.bijectors:
+                if bijector.name == "BatchNorm":
+                    z, log_det = bijector(z, use_last=freeze_bn)
+                else:
+                    n = bijector.count_num_params()
+                    z, log_det = bijector(z, p_dev[:, idx:idx + n])
+                    idx += n
+                log_q = log_q - log_det
+        if home != dev:
+            z, log_q = z.to(home), log_q.to(home)
+        return z, log_q
+
+    # -- density ------------------------------------------------------------
+    def inverse_and_log_det(self, z, params):
+        """Map z back to the base space, accumulating the forward log-dets
+        (density_estimator.py:390-406).  Returns (z0, sum_log_det float32 (M,N))."""
+        if self._fused_ok(z, params):
+            dev = _lib.require_device()
+            mean, alpha = self._bn_stats(dev)
+            _, z0, sld = ops.flow_log_prob_raw(z, params, mean, alpha, self.D, self.num_stages,
+                                               self.num_layers, self.num_units, self.fusion,
+                                               want_z0=True, want_sld=True, want_lp=False)
+            return z0, sld
+        # generic composition: the reference's loop, one HIP kernel per bijector
+        home = z.device
+        dev = _lib.require_device()
+        if home != dev:
+            z = z.to(dev)
+        if params.device != dev:
+            params = params.to(dev)
+        M = max(z.size(0), params.size(0))
+        idx = self.D_params
+        sum_log_det = torch.zeros((M, z.size(1)), device=dev)
+        for bijector in reversed(self.bijectors):
+            n = bijector.count_num_params()
+            if n > 0:
+                z, log_det = bijector.inverse_and_log_det(z, params[:, idx - n:idx])
+                idx -= n
+            else:
+                z, log_det = bijector.inverse_and_log_det(z)
+            sum_log_det = sum_log_det + log_det
+        sum_log_det = sum_log_det.float()  # the reference accumulates into a float32 buffer (:394)
+        if home != dev:
+            z, sum_log_det = z.to(home), sum_log_det.to(home)
+        return z, sum_log_det
+
+    def log_prob(self, z, params=None):
+        """log q(z) (density_estimator.py:408-416)."""
+        if not self.conditioner:
+            params = self.params
+        if self._fused_ok(z, params):
+            dev = _lib.require_device()
+            mean, alpha = self._bn_stats(dev)
+            lp, _, _ = ops.flow_log_prob_raw(z, params, mean, alpha, self.D, self.num_stages,
+                                             self.num_layers, self.num_units, self.fusion)
+            return lp
+        z0, sum_log_det = self.inverse_and_log_det(z, params)
+        log_q = torch.sum(-(z0 ** 2), axis=2) / 2.0 - self.D * np.log(np.sqrt(2.0 * np.pi))
+        return log_q - sum_log_det

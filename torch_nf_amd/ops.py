@@ -1,0 +1,333 @@
+"""Tensor-level wrappers around the C ABI (torch tensors in, torch tensors out).
+
+Everything numerical happens in libtnf_hip.so; torch is used for device memory,
+the current stream, and autograd bookkeeping.  Inputs that live on the host are
+staged to the HIP device and results are handed back on the input's device, so
+code written against the reference (which is CPU-only) keeps working -- but the
+arithmetic always runs on the GPU; there is no CPU implementation here.
+"""
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError("torch_nf_amd kernels take float32 or float64 tensors, not %s" % t.dtype)
+
+
+def _stage(t, dev):
+    """Contiguous copy/view of `t` on the compute device."""
+    if t.device != dev:
+        t = t.to(dev)
+    return t.contiguous()
+
+
+def _rows(params, dev):
+    """(M_p, P) parameter rows with unit inner stride -> (tensor, row_stride)."""
+    if params.dim() != 2:
+        raise ValueError("params must be (M, D_params), got shape %s" % (tuple(params.shape),))
+    if params.device != dev:
+        params = params.to(dev)
+    if params.stride(1) != 1 or (params.shape[0] > 1 and params.stride(0) < params.shape[1]):
+        params = params.contiguous()
+    stride = params.stride(0) if params.shape[0] > 1 else max(params.stride(0), params.shape[1])
+    return params, stride
+
+
+def _bcast_M(Mz, Mp):
+    if Mz != Mp and Mz != 1 and Mp != 1:
+        raise RuntimeError("batch dimensions of z (%d) and params (%d) do not broadcast" % (Mz, Mp))
+    return max(Mz, Mp)
+
+
+def _check3(z):
+    if z.dim() != 3:
+        raise ValueError("z must be (M, N, D), got shape %s" % (tuple(z.shape),))
+
+
+# ---------------------------------------------------------------------------
+# RealNVP coupling layer
+# ---------------------------------------------------------------------------
+def coupling_raw(z, params, D, L, U, upper, inverse):
+    """No-autograd call of tnf_coupling.  Returns (z_out (M,N,D), log_det (M,N))."""
+    _check3(z)
+    dev = _lib.require_device()
+    home = z.device
+    code = _dtype_code(z)
+    if params.dtype != z.dtype:
+        raise TypeError("z (%s) and params (%s) must have the same dtype" % (z.dtype, params.dtype))
+    zc = _stage(z, dev)
+    pc, pstride = _rows(params, dev)
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = _bcast_M(Mz, Mp)
+    if zc.shape[2] != D:
+        raise ValueError("last dimension of z (%d) must equal D (%d)" % (zc.shape[2], D))
+    z_out = torch.empty((M, N, D), dtype=z.dtype, device=dev)
+    log_det = torch.empty((M, N), dtype=z.dtype, device=dev)
+    if N == 0:
+        return z_out.to(home), log_det.to(home)
+    check(lib.tnf_coupling(code, zc.data_ptr(), pc.data_ptr(), z_out.data_ptr(), log_det.data_ptr(),
+                           Mz, Mp, N, D, L, U, int(upper), int(inverse), pstride, _lib.LD_STORE,
+                           _lib.stream_ptr()))
+    if home != dev:
+        z_out, log_det = z_out.to(home), log_det.to(home)
+    return z_out, log_det
+
+
+class _CouplingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, params, D, L, U, upper, inverse):
+        z_out, log_det = coupling_raw(z, params, D, L, U, upper, inverse)
+        ctx.save_for_backward(z, params, z_out)
+        ctx.cfg = (D, L, U, upper, inverse)
+        return z_out, log_det
+
+    @staticmethod
+    def backward(ctx, g_z, g_ld):
+        from . import grad  # backward kernels live behind the same C ABI
+
+        z, params, z_out = ctx.saved_tensors
+        gz, gp = grad.coupling_backward(z, params, z_out, g_z, g_ld, *ctx.cfg)
+        return gz, gp, None, None, None, None, None
+
+
+def coupling(z, params, D, L, U, upper, inverse):
+    if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
+        return _CouplingFn.apply(z, params, D, L, U, upper, inverse)
+    return coupling_raw(z, params, D, L, U, upper, inverse)
+
+
+# ---------------------------------------------------------------------------
+# Affine
+# ---------------------------------------------------------------------------
+def affine_raw(z, params, D, inverse):
+    _check3(z)
+    dev = _lib.require_device()
+    home = z.device
+    code = _dtype_code(z)
+    if params.dtype != z.dtype:
+        raise TypeError("z (%s) and params (%s) must have the same dtype" % (z.dtype, params.dtype))
+    zc = _stage(z, dev)
+    pc, pstride = _rows(params, dev)
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = _bcast_M(Mz, Mp)
+    if zc.shape[2] != D:
+        raise ValueError("last dimension of z (%d) must equal D (%d)" % (zc.shape[2], D))
+    z_out = torch.empty((M, N, D), dtype=z.dtype, device=dev)
+    log_det = torch.empty((Mp, 1), dtype=z.dtype, device=dev)
+    check(lib.tnf_affine(code, zc.data_ptr(), pc.data_ptr(), z_out.data_ptr(), log_det.data_ptr(),
+                         Mz, Mp, N, D, int(inverse), pstride, _lib.stream_ptr()))
+    if home != dev:
+        z_out, log_det = z_out.to(home), log_det.to(home)
+    return z_out, log_det
+
+
+class _AffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, params, D, inverse):
+        z_out, log_det = affine_raw(z, params, D, inverse)
+        ctx.save_for_backward(z, params, z_out)
+        ctx.cfg = (D, inverse)
+        return z_out, log_det
+
+    @staticmethod
+    def backward(ctx, g_z, g_ld):
+        from . import grad
+
+        z, params, z_out = ctx.saved_tensors
+        gz, gp = grad.affine_backward(z, params, z_out, g_z, g_ld, *ctx.cfg)
+        return gz, gp, None, None
+
+
+def affine(z, params, D, inverse):
+    if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
+        return _AffineFn.apply(z, params, D, inverse)
+    return affine_raw(z, params, D, inverse)
+
+
+# ---------------------------------------------------------------------------
+# BatchNorm
+# ---------------------------------------------------------------------------
+def bn_apply_raw(z, mean, alpha, inverse):
+    _check3(z)
+    dev = _lib.require_device()
+    home = z.device
+    code = _dtype_code(z)
+    zc = _stage(z, dev)
+    D = zc.shape[2]
+    mean_c = _stage(mean.detach().float(), dev)
+    alpha_c = _stage(alpha.detach().float(), dev)
+    z_out = torch.empty_like(zc)
+    log_det = torch.empty((), dtype=torch.float32, device=dev)
+    check(lib.tnf_bn_apply(code, zc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(), z_out.data_ptr(),
+                           log_det.data_ptr(), zc.shape[0] * zc.shape[1], D, int(inverse),
+                           _lib.stream_ptr()))
+    if home != dev:
+        z_out, log_det = z_out.to(home), log_det.to(home)
+    return z_out, log_det
+
+
+class _BnApplyFn(torch.autograd.Function):
+    """Cached-statistics BatchNorm; gradients flow to z only (the cached statistics are
+    treated as constants here -- see DESIGN.md, 'BatchNorm and autograd')."""
+
+    @staticmethod
+    def forward(ctx, z, mean, alpha, inverse):
+        z_out, log_det = bn_apply_raw(z, mean, alpha, inverse)
+        ctx.save_for_backward(alpha)
+        ctx.inverse = inverse
+        return z_out, log_det
+
+    @staticmethod
+    def backward(ctx, g_z, g_ld):
+        from . import grad
+
+        (alpha,) = ctx.saved_tensors
+        return grad.bn_apply_backward(g_z, alpha, ctx.inverse), None, None, None
+
+
+def bn_apply(z, mean, alpha, inverse):
+    if torch.is_grad_enabled() and z.requires_grad:
+        return _BnApplyFn.apply(z, mean, alpha, inverse)
+    return bn_apply_raw(z, mean, alpha, inverse)
+
+
+def bn_batch_forward(z, eps):
+    """Batch-statistics BatchNorm forward (float32).  Returns (z_norm, log_det, mean, alpha)."""
+    _check3(z)
+    if z.dtype != torch.float32:
+        raise TypeError("BatchNorm batch statistics are implemented for float32 (got %s)" % z.dtype)
+    dev = _lib.require_device()
+    home = z.device
+    zc = _stage(z.detach(), dev)
+    D = zc.shape[2]
+    rows = zc.shape[0] * zc.shape[1]
+    if rows < 2:
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                         % (torch.Size([rows, D]),))
+    z_out = torch.empty_like(zc)
+    mean = torch.empty(D, dtype=torch.float32, device=dev)
+    alpha = torch.empty(D, dtype=torch.float32, device=dev)
+    log_det = torch.empty((), dtype=torch.float32, device=dev)
+    ws_bytes = lib.tnf_bn_batch_workspace_bytes(D)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.tnf_bn_batch_forward_f32(zc.data_ptr(), z_out.data_ptr(), mean.data_ptr(), alpha.data_ptr(),
+                                       log_det.data_ptr(), rows, D, float(eps), ws.data_ptr(), ws_bytes,
+                                       _lib.stream_ptr()))
+    if home != dev:
+        z_out, log_det, mean, alpha = z_out.to(home), log_det.to(home), mean.to(home), alpha.to(home)
+    return z_out, log_det, mean, alpha
+
+
+# ---------------------------------------------------------------------------
+# base density (float64, like the reference's numpy expression)
+# ---------------------------------------------------------------------------
+def base_log_density_f64(omega):
+    """omega (M,N,D) float64 tensor -> (M,N) float64 log N(omega; 0, I)."""
+    dev = _lib.require_device()
+    home = omega.device
+    oc = _stage(omega.to(torch.float64), dev)
+    M, N, D = oc.shape
+    out = torch.empty((M, N), dtype=torch.float64, device=dev)
+    check(lib.tnf_base_log_density_f64(oc.data_ptr(), out.data_ptr(), M * N, D, _lib.stream_ptr()))
+    return out if home == dev else out.to(home)
+
+
+# ---------------------------------------------------------------------------
+# flow level
+# ---------------------------------------------------------------------------
+def has_fast_path(D, L, U):
+    return bool(lib.tnf_has_fast_path(D, L, U))
+
+
+def resolve_fusion(D, S, L, U, fusion):
+    """AUTO -> the whole-flow kernel when it exists for the shape, else one kernel per layer."""
+    if fusion == _lib.FUSE_AUTO:
+        return _lib.FUSE_FLOW if lib.tnf_flow_fused_supported(D, S, L, U) else _lib.FUSE_LAYER
+    return fusion
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, dev):
+    """Grow-only scratch buffer per (device, stream); the kernels of one call are
+    stream-ordered, so reuse on the same stream is safe."""
+    key = (dev.index, _lib.stream_ptr())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf
+
+
+def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO,
+                      want_z0=False, want_sld=False, want_lp=True):
+    """tnf_flow_log_prob_f32.  Returns (log_prob | None, z0 | None, sum_log_det | None)."""
+    _check3(z)
+    dev = _lib.require_device()
+    home = z.device
+    if z.dtype != torch.float32 or params.dtype != torch.float32:
+        raise TypeError("the fused flow kernels are float32")
+    zc = _stage(z, dev)
+    pc, pstride = _rows(params, dev)
+    mean_c = _stage(bn_mean.detach().float(), dev)
+    alpha_c = _stage(bn_alpha.detach().float(), dev)
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = _bcast_M(Mz, Mp)
+    fusion = resolve_fusion(D, S, L, U, fusion)
+    lp = torch.empty((M, N), dtype=torch.float32, device=dev) if want_lp else None
+    z0 = torch.empty((M, N, D), dtype=torch.float32, device=dev) if want_z0 else None
+    sld = torch.empty((M, N), dtype=torch.float32, device=dev) if want_sld else None
+    if N == 0:
+        return tuple(t.to(home) if t is not None else None for t in (lp, z0, sld))
+    ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, fusion))
+    ws = _workspace(ws_bytes, dev)
+    check(lib.tnf_flow_log_prob_f32(
+        zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+        lp.data_ptr() if want_lp else None, z0.data_ptr() if want_z0 else None,
+        sld.data_ptr() if want_sld else None, Mz, Mp, N, D, S, L, U, pstride, fusion, ws.data_ptr(),
+        ws.numel(), _lib.stream_ptr()))
+    if home != dev:
+        lp = lp.to(home) if want_lp else None
+        z0 = z0.to(home) if want_z0 else None
+        sld = sld.to(home) if want_sld else None
+    return lp, z0, sld
+
+
+def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO):
+    """tnf_flow_forward_f32 (frozen BatchNorm).  Returns (z (M,N,D), sum_log_det (M,N))."""
+    _check3(omega)
+    dev = _lib.require_device()
+    home = omega.device
+    if omega.dtype != torch.float32 or params.dtype != torch.float32:
+        raise TypeError("the fused flow kernels are float32")
+    oc = _stage(omega, dev)
+    pc, pstride = _rows(params, dev)
+    mean_c = _stage(bn_mean.detach().float(), dev)
+    alpha_c = _stage(bn_alpha.detach().float(), dev)
+    Mz, N = oc.shape[0], oc.shape[1]
+    Mp = pc.shape[0]
+    M = _bcast_M(Mz, Mp)
+    fusion = resolve_fusion(D, S, L, U, fusion)
+    z_out = torch.empty((M, N, D), dtype=torch.float32, device=dev)
+    sld = torch.empty((M, N), dtype=torch.float32, device=dev)
+    if N == 0:
+        return z_out.to(home), sld.to(home)
+    ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, fusion))
+    ws = _workspace(ws_bytes, dev)
+    check(lib.tnf_flow_forward_f32(oc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+                                   z_out.data_ptr(), sld.data_ptr(), Mz, Mp, N, D, S, L, U, pstride,
+                                   fusion, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    if home != dev:
+        z_out, sld = z_out.to(home), sld.to(home)
+    return z_out, sld
