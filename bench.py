@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: M samples/s of NormFlow.log_prob, D=64, 8 RealNVP coupling layers
+(num_stages=4, L=2, U=15), N=2^20 samples per GPU, float32, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one NormFlow.log_prob call over one (1, 2^20, 64) batch through the C ABI
+(tnf_flow_log_prob_f32).  The path shards over samples with no data-path collective, so
+with N GPUs every rank evaluates its own 2^20-sample batch (weak scaling) and `value` is
+the samples all ranks processed per second of the slowest rank.
+
+One JSON line is printed by rank 0.  Besides the contract's keys it carries
+  roofline      -- the dominant kernel of the timed path, from HIP events recorded on the
+                   stream the kernels run on, inside the timed region;
+  cpu_baseline  -- the PyTorch-CPU oracle (oracle/flow_oracle.py, verified equal to the
+                   reference in the build container) timed on this box's host cores;
+  layer_chain   -- the same call with one fused kernel per coupling layer (k = 8, the
+                   HBM-bound design), measured after the timed region, with its own roofline;
+  parity        -- max relative error of the GPU log_prob vs the oracle on 2^16 samples.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak (spec)
+
+D, S, L, U = 64, 4, 2, 15
+N_PER_GPU = 1 << 20
+
+
+def flop_per_sample(D, S, L, U):
+    """F_alg = L_c*[4*(h*U + (L-1)*U^2 + U*h) + 2*(L*U + h) + 6h] + 6*D*S + 3*D."""
+    h, Lc = D // 2, 2 * S
+    return Lc * (4 * (h * U + (L - 1) * U * U + U * h) + 2 * (L * U + h) + 6 * h) + 6 * D * S + 3 * D
+
+
+def bytes_per_sample_chain(D, k):
+    """B_alg(k) = 4D(2k-1) + 8(k-1) + 4 for k round trips of z through HBM."""
+    return 4 * D * (2 * k - 1) + 8 * (k - 1) + 4
+
+
+def build_model(tnf, dev):
+    """NormFlow(64, False, 'coupling', 4, 2, 15) with xavier_normal_ params (seed 0) and BatchNorm
+    statistics populated by one 4,096-sample batch-mode forward."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    nf = tnf.NormFlow(D, False, "coupling", S, L, U, device=dev)
+    with torch.no_grad():
+        nf(4096)  # batch-statistics forward on the GPU; caches mean/alpha in every BatchNorm
+    return nf
+
+
+def cpu_baseline(nf, threads):
+    """Time the oracle on the host: same model, same synthetic z (generator seed 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import flow_oracle as orc
+
+    torch.set_num_threads(threads)
+    params = nf.params.detach().cpu()
+    stats = [(b.get_last_mean().cpu(), b.get_last_alpha().cpu()) for b in nf._bn_layers()]
+    n = N_PER_GPU
+    z = torch.randn(1, n, D, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.flow_log_prob(z, params, D, S, L, U, stats)  # warm-up
+        warm = time.perf_counter() - t0
+        if warm > 20.0:  # keep the default run within minutes
+            n = 1 << 18
+            z = z[:, :n].contiguous()
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            orc.flow_log_prob(z, params, D, S, L, U, stats)
+            best = min(best, time.perf_counter() - t0)
+    return {
+        "value": round(n / best / 1e6, 4),
+        "unit": "M samples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "oracle/flow_oracle.py flow_log_prob (PyTorch CPU, fp32, no_grad) on z (1, %d, %d), "
+                  "1 warm-up + best of 3, %d torch threads" % (n, D, threads),
+    }, orc, params, stats
+
+
+def event_ms(pairs):
+    return [a.elapsed_time(b) for a, b in pairs]
+
+
+def read_traffic(kernel_key):
+    """HBM bytes per launch from the committed PMC summary (profiles/*_pmc.json), if any."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel_key]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), 16)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import torch_nf_amd as tnf
+
+    L_ = tnf._lib
+    nf = build_model(tnf, dev)
+    if world > 1:  # identical model everywhere: rank 0's parameters and BatchNorm statistics
+        dist.broadcast(nf.params.data, 0)
+        for b in nf._bn_layers():
+            m, a = b.get_last_mean().clone(), b.get_last_alpha().clone()
+            dist.broadcast(m, 0)
+            dist.broadcast(a, 0)
+            b.set_last_stats(m, a)
+
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    z = torch.randn(1, N_PER_GPU, D, device=dev, generator=gen)  # resident in HBM before timing
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(fusion, steps, warmup):
+        nf.fusion = fusion
+        with torch.no_grad():
+            for _ in range(warmup):
+                nf.log_prob(z)
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                     for _ in range(steps)]
+            barrier()
+            t0 = time.perf_counter()
+            for a, b in pairs:
+                a.record()
+                out = nf.log_prob(z)
+                b.record()
+            barrier()
+            wall = time.perf_counter() - t0
+        return wall, event_ms(pairs), out
+
+    fused = bool(L_.lib.tnf_flow_fused_supported(D, S, L, U))
+    main_fusion = L_.FUSE_FLOW if fused else L_.FUSE_LAYER
+    wall, ev, lp = run(main_fusion, args.steps, args.warmup)
+    wall_t = torch.tensor([wall], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall_max = float(wall_t.item())
+
+    # the per-layer chain (k = 8), outside the timed region
+    wall_l, ev_l, lp_l = run(L_.FUSE_LAYER, max(5, args.steps // 2), 2)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_samples = N_PER_GPU * world * args.steps
+    value = total_samples / wall_max / 1e6
+    flops = flop_per_sample(D, S, L, U)
+    ev_mean = float(np.mean(ev))  # ms per launch of the dominant kernel (+ the 1-block fold kernel)
+    if fused:
+        achieved = N_PER_GPU * flops / (ev_mean * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "flow_fused_kernel<32,2,inverse>", "achieved": round(achieved, 3),
+                    "peak": F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_TFLOPS, 4),
+                    "traffic": read_traffic("flow_fused_kernel"),
+                    "algorithmic_flop_per_sample": flops, "launch_ms": round(ev_mean, 4),
+                    "hbm_compulsory_frac": round(N_PER_GPU * bytes_per_sample_chain(D, 1) / (ev_mean * 1e-3) / 1e9
+                                                 / HBM_PEAK_GBS, 4)}
+    else:
+        roofline = None
+    k = 2 * S
+    evl_mean = float(np.mean(ev_l))
+    chain_bytes = N_PER_GPU * bytes_per_sample_chain(D, k)
+    chain_gbs = chain_bytes / (evl_mean * 1e-3) / 1e9
+    layer_chain = {
+        "value": round(N_PER_GPU / (evl_mean * 1e-3) / 1e6, 2), "unit": "M samples/s", "launches": k,
+        "ms_per_step": round(evl_mean, 4),
+        "roofline": {"bound": "hbm", "kernel": "coupling_mfma_kernel<32,2,inverse>",
+                     "achieved": round(chain_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(chain_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": read_traffic("coupling_mfma_kernel"),
+                     "algorithmic_bytes_per_sample_all_launches": bytes_per_sample_chain(D, k)},
+    }
+    if roofline is None:
+        roofline = layer_chain["roofline"]
+
+    out = {
+        "metric": "M samples/sec NormFlow.log_prob, D=64 RealNVPx8, N=2^20",
+        "value": round(value, 2),
+        "unit": "M samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall_max / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "NormFlow(64,False,'coupling',num_stages=4,num_layers=2,num_units=15).log_prob, "
+                               "z (1, 2^20, 64) fp32 per GPU resident in HBM, xavier params seed 0, "
+                               "BN stats from one 4096-sample forward",
+                   "samples_per_gpu": N_PER_GPU, "D": D, "coupling_layers": 2 * S,
+                   "fusion": "whole-flow kernel (k=1)" if fused else "one kernel per coupling layer (k=8)",
+                   "sharding": "samples, no collective in the timed region"},
+        "roofline": roofline,
+        "layer_chain": layer_chain,
+    }
+
+    if not args.no_cpu_baseline and world == 1:
+        threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+        base, orc, params, stats = cpu_baseline(nf, threads)
+        out["cpu_baseline"] = base
+        sl = slice(1 << 19, (1 << 19) + (1 << 16))
+        with torch.no_grad():
+            want = orc.flow_log_prob(z[:, sl].cpu(), params, D, S, L, U, stats)
+        rel = ((lp[:, sl].cpu() - want).abs() / want.abs().clamp_min(1e-3)).max().item()
+        rel_l = ((lp_l[:, sl].cpu() - want).abs() / want.abs().clamp_min(1e-3)).max().item()
+        out["parity"] = {"max_rel_err_vs_oracle": float("%.3g" % rel), "layer_chain_max_rel_err": float("%.3g" % rel_l),
+                         "samples": 1 << 16, "tolerance": 1e-5}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
