@@ -63,7 +63,11 @@ const char* tnf_last_error(void);
 
 /* Testing hooks.  TNF_OPT_FORCE_GENERIC != 0 makes tnf_coupling skip the MFMA
  * specialisations so the tests can compare both kernels on the same inputs. */
-enum { TNF_OPT_FORCE_GENERIC = 1 };
+enum {
+    TNF_OPT_FORCE_GENERIC = 1,
+    TNF_OPT_FLOW_VARIANT = 2,  /* tuning: (tiles per wave, waves per workgroup) of the whole-flow kernel */
+    TNF_OPT_LAYER_VARIANT = 3  /* tuning: launch geometry of the per-layer kernel */
+};
 int tnf_set_option(int32_t key, int32_t value);
 
 /* Number of packed parameters of one RealNVP layer / of the whole coupling flow.
@@ -114,6 +118,27 @@ int64_t tnf_bn_batch_workspace_bytes(int32_t D);
 int tnf_bn_batch_forward_f32(const float* z, float* z_out, float* mean_out, float* alpha_out,
                              float* log_det, int64_t rows, int32_t D, float eps, void* workspace,
                              int64_t workspace_bytes, void* stream);
+
+/* ---- backward passes (what torch autograd derives for the reference) ----------------
+ * Each recomputes the layer from its saved INPUT z; nothing else is kept from the forward
+ * pass.  g_z_out / g_log_det are the gradients w.r.t. the forward outputs; g_z receives the
+ * gradient w.r.t. z (M,N,D) and g_params ACCUMULATES (float atomics; zero it first) the
+ * gradient w.r.t. the packed parameter rows (M_p rows of g_params_row_stride elements).
+ * z must already be broadcast to M rows (M_p is 1 or M). */
+int tnf_coupling_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+                          const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
+                          int64_t N, int32_t D, int32_t num_layers, int32_t num_units,
+                          int32_t transform_upper, int32_t inverse, int64_t params_row_stride,
+                          int64_t g_params_row_stride, void* stream);
+/* g_log_det is (M_p, 1) like the forward log_det. */
+int tnf_affine_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+                        const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
+                        int64_t N, int32_t D, int32_t inverse, int64_t params_row_stride,
+                        int64_t g_params_row_stride, void* stream);
+/* Cached-statistics BatchNorm: g_z = g_z_out * alpha (inverse) or / alpha (frozen forward);
+ * the statistics are constants of the graph. */
+int tnf_bn_apply_backward(int32_t dtype, const void* g_z_out, const float* alpha, void* g_z, int64_t rows,
+                          int32_t D, int32_t inverse, void* stream);
 
 /* Base density of NormFlow.forward, float64 like the reference's numpy expression
  * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as

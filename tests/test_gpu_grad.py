@@ -1,0 +1,128 @@
+"""Gradients of the HIP path (hand-written backward kernels behind torch.autograd.Function)
+against torch autograd over the CPU oracle and against the reference's own gradients
+(tests/golden/flow.npz: d(-mean log_prob)/d params and /d z for the D=64, 4-stage model)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tnf():
+    import torch_nf_amd
+
+    assert torch.cuda.is_available()
+    return torch_nf_amd
+
+
+def T(a, dev="cuda"):
+    return torch.from_numpy(np.array(a)).to(dev)
+
+
+@pytest.mark.parametrize("D,L,U,upper,Mz,Mp,N,dtype", [
+    (8, 2, 15, True, 3, 3, 7, torch.float64), (5, 1, 15, False, 2, 2, 9, torch.float64),
+    (5, 3, 17, True, 2, 1, 5, torch.float64),
+    (64, 2, 15, True, 1, 1, 300, torch.float32), (32, 2, 15, False, 4, 4, 33, torch.float32),
+    (64, 2, 40, False, 1, 1, 70, torch.float32),
+])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_coupling_grad(tnf, oracle, D, L, U, upper, Mz, Mp, N, dtype, inverse):
+    rng = np.random.RandomState(D * 7 + N)
+    layer = tnf.RealNVP(D, L, U, transform_upper=upper)
+    p0 = torch.tensor(rng.normal(0, 0.2, (Mp, layer.count_num_params()))).to(dtype)
+    z0 = torch.tensor(rng.normal(0, 1, (Mz, N, D))).to(dtype)
+    M = max(Mz, Mp)
+    wz = torch.tensor(rng.normal(0, 1, (M, N, D))).to(dtype)
+    wl = torch.tensor(rng.normal(0, 1, (M, N))).to(dtype)
+
+    def loss(zo, ld, wz, wl):
+        return (zo * wz).sum() + (ld * wl).sum()
+
+    p_ref, z_ref = p0.clone().requires_grad_(), z0.clone().requires_grad_()
+    loss(*oracle.coupling(z_ref, p_ref, D, L, U, upper, inverse), wz, wl).backward()
+    p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
+    fn = layer.inverse_and_log_det if inverse else layer.forward_and_log_det
+    loss(*fn(z, p), wz.cuda(), wl.cuda()).backward()
+    tol = dict(rtol=1e-9, atol=1e-9) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(z.grad.cpu(), z_ref.grad, **tol)
+    torch.testing.assert_close(p.grad.cpu(), p_ref.grad, **tol)
+
+
+@pytest.mark.parametrize("Mz,Mp", [(3, 3), (3, 1), (1, 4)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_and_bn_grad(tnf, oracle, Mz, Mp, inverse):
+    D, N = 6, 11
+    rng = np.random.RandomState(3)
+    p0 = torch.tensor(rng.normal(0, 0.5, (Mp, 2 * D)))
+    z0 = torch.tensor(rng.normal(0, 1, (Mz, N, D)))
+    M = max(Mz, Mp)
+    wz = torch.tensor(rng.normal(0, 1, (M, N, D)))
+    wl = torch.tensor(rng.normal(0, 1, (Mp, 1)))
+    p_ref, z_ref = p0.clone().requires_grad_(), z0.clone().requires_grad_()
+    zo, ld = oracle.affine(z_ref, p_ref, D, inverse)
+    ((zo * wz).sum() + (ld * wl).sum()).backward()
+    p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
+    aff = tnf.Affine(D)
+    zo, ld = (aff.inverse_and_log_det if inverse else aff.forward_and_log_det)(z, p)
+    ((zo * wz.cuda()).sum() + (ld * wl.cuda()).sum()).backward()
+    torch.testing.assert_close(z.grad.cpu(), z_ref.grad, rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(p.grad.cpu(), p_ref.grad, rtol=1e-9, atol=1e-9)
+    # BatchNorm with cached statistics: gradient w.r.t. z
+    bn = tnf.BatchNorm(D)
+    mean = torch.tensor(rng.normal(0, 1, D)).float()
+    alpha = torch.tensor(np.exp(rng.normal(0, 0.3, D))).float()
+    bn.set_last_stats(mean.cuda(), alpha.cuda())
+    zb = z0.cuda().requires_grad_()
+    zo, _ = bn.inverse_and_log_det(zb) if inverse else bn(zb, use_last=True)
+    (zo * wz[:Mz].cuda()).sum().backward()
+    zr = z0.clone().requires_grad_()
+    zo_ref, _ = (oracle.bn_inverse if inverse else oracle.bn_forward_frozen)(zr, mean, alpha)
+    (zo_ref * wz[:Mz]).sum().backward()
+    torch.testing.assert_close(zb.grad.cpu(), zr.grad, rtol=1e-6, atol=1e-6)
+
+
+def test_golden_flow_gradients(tnf):
+    """-mean(log_prob) of NormFlow(64, coupling, 4 stages): gradients vs the reference's autograd."""
+    g = load_golden("flow")
+    metas = g["meta"].tolist()
+    ci = [i for i in range(len(metas)) if "f%02d_grad_params" % i in g][0]
+    D, S, L, U, N = metas[ci]
+    k = "f%02d_" % ci
+    nf = tnf.NormFlow(D, False, "coupling", S, L, U)
+    nf.params = T(g[k + "params"]).requires_grad_()
+    for b, m, a in zip(nf._bn_layers(), g[k + "bn_mean"], g[k + "bn_alpha"]):
+        b.set_last_stats(T(m), T(a))
+    z = T(g[k + "z_test"]).requires_grad_()
+    loss = -torch.mean(nf.log_prob(z))
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), T(g[k + "loss"], "cpu"), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(nf.params.grad.cpu(), T(g[k + "grad_params"], "cpu"), rtol=2e-4, atol=2e-6)
+    torch.testing.assert_close(z.grad.cpu(), T(g[k + "grad_z"], "cpu"), rtol=2e-4, atol=1e-7)
+
+
+def test_cde_training_step(tnf, oracle):
+    """SNPE-style step (notebooks/LFI_learning_rules.ipynb:295-304 of the reference):
+    loss = -mean(cde.log_prob(z[:, None, :], x)); gradients reach param_net through the kernels."""
+    D, S, L, U, D_x, M = 4, 1, 2, 15, 3, 64
+    torch.manual_seed(0)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    cde = tnf.ConditionalDensityEstimator(nf, D_x, [16])
+    rng = np.random.RandomState(0)
+    x = torch.tensor(rng.normal(0, 1, (M, D_x))).float().cuda()
+    z = torch.tensor(rng.normal(0, 1, (M, 1, D))).float().cuda()
+    loss = -cde.log_prob(z, x).mean()
+    loss.backward()
+    # same computation with the oracle on the CPU, sharing the param_net weights
+    net = torch.nn.Sequential(torch.nn.Linear(D_x, 16), torch.nn.Tanh(), torch.nn.Linear(16, nf.D_params))
+    net.load_state_dict({k2: v.detach().cpu() for k2, v in zip(net.state_dict().keys(), cde.param_net.state_dict().values())})
+    stats = [(b.get_last_mean().cpu(), b.get_last_alpha().cpu()) for b in nf._bn_layers()]
+    ref = -oracle.flow_log_prob(z.cpu(), net(x.cpu()), D, S, L, U, stats).mean()
+    ref.backward()
+    torch.testing.assert_close(loss.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    for got, want in zip(cde.param_net.parameters(), net.parameters()):
+        torch.testing.assert_close(got.grad.cpu(), want.grad, rtol=1e-3, atol=1e-4)  # param_net GEMMs: hipBLASLt vs MKL
+    opt = torch.optim.Adam(cde.parameters(), lr=1e-3)
+    opt.step()

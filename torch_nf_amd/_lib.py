@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtnf_hip.so")
 F32, F64 = 0, 1
 LD_STORE, LD_ADD, LD_SUB = 0, 1, -1
 FUSE_AUTO, FUSE_LAYER, FUSE_FLOW = 0, 1, 2
-OPT_FORCE_GENERIC = 1
+OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT = 1, 2, 3
 EUNSUPPORTED = -2
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
@@ -35,6 +35,11 @@ SIGNATURES = {
     "tnf_bn_apply": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_bn_batch_workspace_bytes": (_i64, [_i32]),
     "tnf_bn_batch_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
+    "tnf_coupling_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                             _i32, _i32, _i32, _i64, _i64, _vp]),
+    "tnf_affine_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                           _i64, _i64, _vp]),
+    "tnf_bn_apply_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_base_log_density_f64": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "tnf_flow_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32]),
     "tnf_flow_fused_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),

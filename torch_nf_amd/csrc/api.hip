@@ -40,13 +40,15 @@ static int check_mnd(const char* fn, int64_t Mz, int64_t Mp, int64_t N, int D) {
 static int64_t round16(int64_t b) { return (b + 15) & ~(int64_t)15; }
 
 struct FlowWs {
-    int64_t fold, ldc, zbuf, ldbuf, total;
+    int64_t fold, ldc, images, zbuf, ldbuf, total;
 };
 static FlowWs flow_ws(int64_t M, int64_t N, int D, int S) {
     FlowWs w;
     w.fold = 0;
     w.ldc = round16(M * 2 * S * 2 * D * (int64_t)sizeof(float));
-    w.zbuf = w.ldc + round16(M * (int64_t)sizeof(float));
+    w.images = w.ldc + round16(M * (int64_t)sizeof(float));
+    // operand images sized for the widest supported MLP (L = 3): the size query does not know L
+    w.zbuf = w.images + round16(M * 2 * S * mfma_image_floats(D, 3) * (int64_t)sizeof(float));
     w.ldbuf = w.zbuf + round16(M * N * D * (int64_t)sizeof(float));
     w.total = w.ldbuf + round16(M * N * (int64_t)sizeof(float));
     return w;
@@ -65,6 +67,14 @@ const char* tnf_last_error(void) { return err_buf(); }
 int tnf_set_option(int32_t key, int32_t value) {
     if (key == TNF_OPT_FORCE_GENERIC) {
         g_force_generic = value;
+        return TNF_OK;
+    }
+    if (key == TNF_OPT_FLOW_VARIANT) {
+        g_flow_variant = value;
+        return TNF_OK;
+    }
+    if (key == TNF_OPT_LAYER_VARIANT) {
+        g_layer_variant = value;
         return TNF_OK;
     }
     return fail(TNF_EINVAL, "tnf_set_option: unknown key %d", key);
@@ -159,6 +169,49 @@ int tnf_bn_batch_forward_f32(const float* z, float* z_out, float* mean_out, floa
                                    as_stream(stream));
 }
 
+int tnf_coupling_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+                          const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
+                          int64_t N, int32_t D, int32_t L, int32_t U, int32_t upper, int32_t inverse,
+                          int64_t pstride, int64_t gpstride, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_coupling_backward: dtype %d", dtype);
+    if (M < 1 || N < 0 || D < 2 || L < 1 || U < 1 || (M_p != 1 && M_p != M))
+        return fail(TNF_EINVAL, "tnf_coupling_backward: M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", (long long)M,
+                    (long long)M_p, (long long)N, D, L, U);
+    const int64_t need = coupling_num_params(D, L, U, upper);
+    if (pstride < need || gpstride < need)
+        return fail(TNF_EINVAL, "tnf_coupling_backward: parameter rows (%lld / %lld) shorter than %lld",
+                    (long long)pstride, (long long)gpstride, (long long)need);
+    if (!z || !params || !g_z_out || !g_log_det || !g_z || !g_params)
+        return fail(TNF_EINVAL, "tnf_coupling_backward: NULL pointer");
+    if (N == 0) return TNF_OK;
+    return launch_coupling_backward(dtype, z, params, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
+                                    upper, inverse, pstride, gpstride, as_stream(stream));
+}
+
+int tnf_affine_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+                        const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
+                        int64_t N, int32_t D, int32_t inverse, int64_t pstride, int64_t gpstride,
+                        void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_affine_backward: dtype %d", dtype);
+    if (M < 1 || N < 0 || D < 1 || (M_p != 1 && M_p != M))
+        return fail(TNF_EINVAL, "tnf_affine_backward: M=%lld M_p=%lld N=%lld D=%d", (long long)M, (long long)M_p,
+                    (long long)N, D);
+    if (pstride < 2 * (int64_t)D || gpstride < 2 * (int64_t)D)
+        return fail(TNF_EINVAL, "tnf_affine_backward: parameter rows shorter than %d", 2 * D);
+    if (!params || !g_log_det || !g_params || (N > 0 && (!z || !g_z_out || !g_z)))
+        return fail(TNF_EINVAL, "tnf_affine_backward: NULL pointer");
+    return launch_affine_backward(dtype, z, params, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, inverse,
+                                  pstride, gpstride, as_stream(stream));
+}
+
+int tnf_bn_apply_backward(int32_t dtype, const void* g_z_out, const float* alpha, void* g_z, int64_t rows,
+                          int32_t D, int32_t inverse, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_bn_apply_backward: dtype %d", dtype);
+    if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_bn_apply_backward: rows=%lld D=%d", (long long)rows, D);
+    if (!alpha || (rows > 0 && (!g_z_out || !g_z))) return fail(TNF_EINVAL, "tnf_bn_apply_backward: NULL pointer");
+    return launch_bn_apply_backward(dtype, g_z_out, alpha, g_z, rows, D, inverse, as_stream(stream));
+}
+
 int tnf_base_log_density_f64(const double* omega, double* out, int64_t rows, int32_t D, void* stream) {
     if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_base_log_density_f64: rows=%lld D=%d", (long long)rows, D);
     if (!omega || !out) return fail(TNF_EINVAL, "tnf_base_log_density_f64: NULL pointer");
@@ -223,11 +276,13 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
     char* wsb = reinterpret_cast<char*>(workspace);
     float* fold = reinterpret_cast<float*>(wsb + w.fold);
     float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
-    rc = launch_flow_fold(params, bn_mean, bn_alpha, fold, ldc, M_p, D, S, L, U, pstride, 1, st);
+    float* images = reinterpret_cast<float*>(wsb + w.images);
+    const int64_t img_floats = mfma_image_floats(D, L);
+    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 1, st);
     if (rc) return rc;
     if (use_fused)
-        return launch_flow_fused(z, params, fold, ldc, z0, sum_log_det, log_prob, M_z, M_p, N, D, S,
-                                 L, U, pstride, 1, st);
+        return launch_flow_fused(z, images, fold, ldc, z0, sum_log_det, log_prob, M_z, M_p, N, D, S,
+                                 L, U, 1, st);
     // one launch per coupling layer, last forward layer first
     float* zbuf = z0 ? z0 : reinterpret_cast<float*>(wsb + w.zbuf);
     float* ldbuf = sum_log_det ? sum_log_det : reinterpret_cast<float*>(wsb + w.ldbuf);
@@ -241,6 +296,8 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
         a.z_out = (last && !z0) ? nullptr : zbuf;
         a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
         a.pstride = pstride;
+        a.image = images + (int64_t)c * img_floats;
+        a.image_stride = (int64_t)nl * img_floats;
         a.pre = fold + (int64_t)c * 2 * D;
         a.fold_stride = (int64_t)nl * 2 * D;
         a.ld_in = first ? nullptr : ldbuf;
@@ -278,11 +335,13 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
     char* wsb = reinterpret_cast<char*>(workspace);
     float* fold = reinterpret_cast<float*>(wsb + w.fold);
     float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
-    rc = launch_flow_fold(params, bn_mean, bn_alpha, fold, ldc, M_p, D, S, L, U, pstride, 0, st);
+    float* images = reinterpret_cast<float*>(wsb + w.images);
+    const int64_t img_floats = mfma_image_floats(D, L);
+    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 0, st);
     if (rc) return rc;
     if (use_fused)
-        return launch_flow_fused(omega, params, fold, ldc, z_out, sum_log_det, nullptr, M_z, M_p, N,
-                                 D, S, L, U, pstride, 0, st);
+        return launch_flow_fused(omega, images, fold, ldc, z_out, sum_log_det, nullptr, M_z, M_p, N,
+                                 D, S, L, U, 0, st);
     const FlowLayout fl = flow_layout(D, S, L, U);
     const int nl = 2 * S;
     for (int c = 0; c < nl; ++c) {
@@ -293,6 +352,8 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
         a.z_out = z_out;
         a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
         a.pstride = pstride;
+        a.image = images + (int64_t)c * img_floats;
+        a.image_stride = (int64_t)nl * img_floats;
         a.post = fold + (int64_t)c * 2 * D;
         a.fold_stride = (int64_t)nl * 2 * D;
         a.ld_in = first ? nullptr : sum_log_det;

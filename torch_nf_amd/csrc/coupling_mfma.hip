@@ -61,12 +61,48 @@ flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_
     if (threadIdx.x == 0) ldc[m] = red[0];
 }
 
-int launch_flow_fold(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
-                     float* ldc, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
-                     int inverse, hipStream_t st) {
+// ---------------------------------------------------------------------------
+// Build every layer's MFMA operand image once per call (one wave per (layer, context)):
+// the gather from the packed parameter row, the activation folding and the column sums
+// happen here, so the hot kernels start from coalesced float4 loads of a lane-ordered
+// image ((4HT + 2(L-1)) x 1 KB of weights + bias groups) instead of ~90 scattered loads.
+// images: (Mp, 2S, image_floats) floats.
+// ---------------------------------------------------------------------------
+template <int H, int L>
+__global__ void __launch_bounds__(64)
+flow_images_kernel(const float* __restrict__ params, float* __restrict__ images, int S, int U,
+                   int64_t pstride, int64_t image_floats) {
+    constexpr int D = 2 * H;
+    const int c = blockIdx.x;
+    const int64_t m = blockIdx.y;
+    const int64_t pc = coupling_num_params(D, L, U, 1);
+    const int64_t stage = 2 * pc + 2 * D;
+    LayerW<H, L> w;
+    load_layer_w<H, L>(w, params + m * pstride + (c >> 1) * stage + (c & 1) * pc, U, threadIdx.x);
+    store_layer_image<H, L>(images + (m * 2 * S + c) * image_floats, w, threadIdx.x);
+}
+
+int64_t mfma_image_floats(int D, int L) {
+    const int HT = (D / 2 + 15) / 16;
+    return (int64_t)(4 * HT + 2 * (L - 1)) * 256 + (2 + 2 * (L - 1) + 2 * HT) * 16;
+}
+
+int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
+                     float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
+                     int64_t pstride, int inverse, hipStream_t st) {
     hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
                        bn_alpha, fold, ldc, D, S, L, U, pstride, inverse);
-    return check_launch("flow_fold");
+    const dim3 grid((unsigned)(2 * S), (unsigned)Mp);
+    const int64_t fl = mfma_image_floats(D, L);
+#define TNF_IMG(HH, LL) \
+    hipLaunchKernelGGL((flow_images_kernel<HH, LL>), grid, dim3(64), 0, st, params, images, S, U, pstride, fl)
+    if (D == 64) {
+        if (L == 1) TNF_IMG(32, 1); else if (L == 2) TNF_IMG(32, 2); else TNF_IMG(32, 3);
+    } else {
+        if (L == 1) TNF_IMG(16, 1); else if (L == 2) TNF_IMG(16, 2); else TNF_IMG(16, 3);
+    }
+#undef TNF_IMG
+    return check_launch("flow_prep");
 }
 
 // ---------------------------------------------------------------------------
@@ -74,12 +110,13 @@ int launch_flow_fold(const float* params, const float* bn_mean, const float* bn_
 // operands in registers and walks 16-sample tiles grid-stride, with the next tile's
 // loads in flight during the current tile's arithmetic.
 // ---------------------------------------------------------------------------
-template <int H, int L, bool INV, int NT>
+template <int H, int L, bool INV, int NT, bool LDSOP>
 __global__ void __launch_bounds__(256)
 coupling_mfma_kernel(MfmaLayerArgs a) {
     constexpr int D = 2 * H;
     constexpr int HT = (H + 15) / 16;
-    __shared__ __attribute__((aligned(16))) float cfold[4 * D];  // pre A|B, post A|B
+    typedef LdsLayerImage<H, L> Img;
+    __shared__ __attribute__((aligned(16))) float cfold[4 * D + (LDSOP ? Img::FLOATS : 0)];  // pre A|B, post A|B, [image]
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -93,9 +130,41 @@ coupling_mfma_kernel(MfmaLayerArgs a) {
         cfold[2 * D + i] = has_post ? a.post[mp * a.fold_stride + i] : 0.f;
     }
 
+    // Operands: registers (LayerW, 72 VGPRs, no LDS traffic in the loop) or an LDS copy of the
+    // prepared image (frees the registers for a third / fourth wave per SIMD).
     LayerW<H, L> w;
-    load_layer_w<H, L>(w, a.params + mp * a.pstride, a.U, lane);
-    const RegOperands<H, L> op{w};
+    if constexpr (LDSOP) {
+        const f4* isrc = reinterpret_cast<const f4*>(a.image + mp * a.image_stride);
+        f4* idst = reinterpret_cast<f4*>(cfold + 4 * D);
+        for (int i = threadIdx.x; i < Img::FLOATS / 4; i += 256) idst[i] = isrc[i];
+    } else if (a.image) {  // flow-level chains: lane-ordered image prepared by flow_images_kernel
+        const LdsOperands<H, L> src(a.image + mp * a.image_stride, lane);
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                const f4 v0 = src.w0(net, mm), v2 = src.w2(net, mm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w.w0[net][mm * 4 + j] = v0[j];
+                    w.w2[net][mm][j] = v2[j];
+                }
+                w.b2[net][mm] = src.b2(net, mm);
+            }
+#pragma unroll
+            for (int l = 0; l < L - 1; ++l) {
+                const f4 vh = src.wh(l, net);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w.wh[l][net][j] = vh[j];
+                w.bh[l][net] = src.bh(l, net);
+            }
+            w.b0[net] = src.b0(net);
+        }
+    } else {  // bijector-level call: gather straight from the packed parameter row
+        load_layer_w<H, L>(w, a.params + mp * a.pstride, a.U, lane);
+    }
+    const RegOperands<H, L> rop{w};
+    const LdsOperands<H, L> lop(cfold + 4 * D, lane);
     __syncthreads();
 
     const int c_off = a.upper ? 0 : H;
@@ -172,7 +241,12 @@ coupling_mfma_kernel(MfmaLayerArgs a) {
         float ssum[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) ssum[t] = 0.f;
-        coupling_tile<H, L, INV, NT>(op, x, y, ssum);
+        if constexpr (LDSOP) {
+            asm volatile("" ::: "memory");  // keep the operand reads in the loop (no hoisting back into VGPRs)
+            coupling_tile<H, L, INV, NT>(lop, x, y, ssum);
+        }
+        else
+            coupling_tile<H, L, INV, NT>(rop, x, y, ssum);
         if (has_post) {
 #pragma unroll
             for (int mm = 0; mm < HT; ++mm) {
@@ -193,7 +267,7 @@ coupling_mfma_kernel(MfmaLayerArgs a) {
         for (int t = 0; t < NT; ++t) {
             const int64_t row = (grp * NT + t) * 16 + s;
             const bool row_ok = row < a.N;
-            const float sred = reduce_q(ssum[t]);
+            const float sred = reduce_q(ssum[t]) * kLn2;  // the tile code sums s*log2(e)
             float ld_tot = __builtin_fmaf(a.ld_sign, sred, ld_prev[t]);
             if (a.add_ldc) ld_tot += ldc;
             if (lpo) {
@@ -229,22 +303,37 @@ bool mfma_supported(int D, int L, int U) {
     return U >= 1 && U <= 16;
 }
 
-constexpr int kLayerNT = 2;  // 16-sample tiles per wave iteration
+// Launch-geometry variants (g_layer_variant, TNF_OPT_LAYER_VARIANT):
+//   0: operands in registers, 2 tiles per wave iteration     1: operands in LDS, 2 tiles
+//   2: operands in LDS, 1 tile                               3: operands in registers, 1 tile
+int g_layer_variant = 0;
 
-template <int H, int L>
-static void launch_hl(const MfmaLayerArgs& a, dim3 grid, hipStream_t st) {
-    if (a.inverse)
-        hipLaunchKernelGGL((coupling_mfma_kernel<H, L, true, kLayerNT>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((coupling_mfma_kernel<H, L, false, kLayerNT>), grid, dim3(256), 0, st, a);
+template <int H, int L, bool INV, int NT, bool LDSOP>
+static void launch_k(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {
+    const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
+    int64_t bx = (ngroups + 3) / 4;
+    int64_t cap = 2048 / M;
+    if (cap < 1) cap = 1;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL((coupling_mfma_kernel<H, L, INV, NT, LDSOP>), dim3((unsigned)bx, (unsigned)M), dim3(256),
+                       0, st, a);
+}
+
+template <int H, int L, bool INV>
+static void launch_v(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {
+    const int v = a.image ? g_layer_variant : 0;  // the LDS variants need the prepared image
+    if (L == 2 && v == 1) launch_k<H, L, INV, 2, true>(a, M, st);
+    else if (L == 2 && v == 2) launch_k<H, L, INV, 1, true>(a, M, st);
+    else if (L == 2 && v == 3) launch_k<H, L, INV, 1, false>(a, M, st);
+    else launch_k<H, L, INV, 2, false>(a, M, st);
 }
 
 template <int H>
-static void launch_h(const MfmaLayerArgs& a, dim3 grid, hipStream_t st) {
+static void launch_h(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {
     switch (a.L) {
-        case 1: launch_hl<H, 1>(a, grid, st); break;
-        case 2: launch_hl<H, 2>(a, grid, st); break;
-        default: launch_hl<H, 3>(a, grid, st); break;
+        case 1: a.inverse ? launch_v<H, 1, true>(a, M, st) : launch_v<H, 1, false>(a, M, st); break;
+        case 2: a.inverse ? launch_v<H, 2, true>(a, M, st) : launch_v<H, 2, false>(a, M, st); break;
+        default: a.inverse ? launch_v<H, 3, true>(a, M, st) : launch_v<H, 3, false>(a, M, st); break;
     }
 }
 
@@ -254,14 +343,8 @@ int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st) {
     const int64_t M = a.Mz > a.Mp ? a.Mz : a.Mp;
     if (M > 65535) return fail(TNF_EUNSUPPORTED, "coupling_mfma: M=%lld too large", (long long)M);
     if (a.N <= 0) return TNF_OK;
-    const int64_t ngroups = (a.N + 16 * kLayerNT - 1) / (16 * kLayerNT);
-    int64_t bx = (ngroups + 3) / 4;
-    int64_t cap = 2048 / M;
-    if (cap < 1) cap = 1;
-    if (bx > cap) bx = cap;
-    dim3 grid((unsigned)bx, (unsigned)M);
-    if (a.D == 64) launch_h<32>(a, grid, st);
-    else launch_h<16>(a, grid, st);
+    if (a.D == 64) launch_h<32>(a, M, st);
+    else launch_h<16>(a, M, st);
     return check_launch("coupling_mfma");
 }
 

@@ -5,6 +5,9 @@
 // S=4 of the 160 KB per CU), fetched with ds_read_b128 per 4 K-steps and shared by
 // the NT tiles a wave processes per iteration.  Compulsory HBM traffic: 4D+4 B/sample,
 // so this kernel is bound by the fp32 matrix/vector pipes, not by HBM.
+#ifndef TNF_STAMP
+#define TNF_STAMP 0
+#endif
 #include "mfma_tile.h"
 #include "tnf_common.h"
 
@@ -12,13 +15,13 @@ namespace tnf {
 
 struct FlowFusedArgs {
     const float* z;
-    const float* params;
-    const float* fold;  // (Mp, 2S, 2, D)
+    const float* images;  // (Mp, 2S, Img::FLOATS) lane-ordered MFMA operands (flow_images_kernel)
+    const float* fold;    // (Mp, 2S, 2, D)
     const float* ldc;   // (Mp)
     float* z_out;       // optional
     float* sum_log_det; // optional
     float* log_prob;    // optional (inverse only)
-    int64_t Mz, Mp, N, pstride;
+    int64_t Mz, Mp, N;
     int S, U;
 };
 
@@ -43,7 +46,7 @@ __device__ __forceinline__ void apply_fold(const float* fc, int q, f4 (&lo)[NT][
     }
 }
 
-template <int H, int L, bool INV, int NT, int NWAVES>
+template <int H, int L, bool INV, int NT, int NWAVES, bool SKEW>
 __global__ void __launch_bounds__(NWAVES * 64)
 flow_fused_kernel(FlowFusedArgs a) {
     constexpr int D = 2 * H;
@@ -59,19 +62,22 @@ flow_fused_kernel(FlowFusedArgs a) {
     const int s = lane & 15, q = lane >> 4;
     const int64_t m = blockIdx.y;
     const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
+#if TNF_STAMP
+    const unsigned long long st_e0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    {   // build the LDS operand images (one layer per wave at a time)
-        const int64_t pc = coupling_num_params(D, L, a.U, 1);
-        const int64_t stage = 2 * pc + 2 * D;
-        const float* prow = a.params + mp * a.pstride;
-        for (int c = wave; c < nl; c += NWAVES) {
-            LayerW<H, L> w;
-            load_layer_w<H, L>(w, prow + (c >> 1) * stage + (c & 1) * pc, a.U, lane);
-            store_layer_image<H, L>(img + c * Img::FLOATS, w, lane);
-        }
+    {   // stage all layers' operand images and fold constants in LDS (coalesced float4 copies)
+        const f4* isrc = reinterpret_cast<const f4*>(a.images + mp * (int64_t)nl * Img::FLOATS);
+        f4* idst = reinterpret_cast<f4*>(img);
+        for (int i = threadIdx.x; i < nl * (Img::FLOATS / 4); i += NWAVES * 64) idst[i] = isrc[i];
         const float* fsrc = a.fold + mp * (int64_t)nl * 2 * D;
         for (int i = threadIdx.x; i < nl * 2 * D; i += NWAVES * 64) fold[i] = fsrc[i];
     }
+    // Work queue of this workgroup: the two waves that share a SIMD do not progress at the same
+    // rate (issue arbitration favours the older one: 330 vs 505 us for equal static shares), so
+    // the waves pull 32-sample groups from an LDS counter instead of owning a fixed stride.
+    int* qhead = reinterpret_cast<int*>(fold + nl * 2 * D);
+    if (threadIdx.x == 0) *qhead = NWAVES;
     __syncthreads();
 
     const float* zb = a.z + mz * a.N * D;
@@ -81,9 +87,14 @@ flow_fused_kernel(FlowFusedArgs a) {
     const float ldc = a.ldc[mp];
 
     const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
-    const int64_t gstride = (int64_t)gridDim.x * NWAVES;
-    int64_t grp = (int64_t)blockIdx.x * NWAVES + wave;
-    if (grp >= ngroups) return;
+    const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
+    const int64_t g_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t g_hi = (g_lo + per_block < ngroups) ? g_lo + per_block : ngroups;
+    int64_t grp = g_lo + wave;
+    if (grp >= g_hi) return;
+#if TNF_STAMP  // diagnostic build only: in-kernel clock = d(s_memtime)/d(s_memrealtime) * 100 MHz
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     f4 nlo[NT][HT], nhi[NT][HT];
 #pragma unroll
@@ -98,7 +109,19 @@ flow_fused_kernel(FlowFusedArgs a) {
         }
     }
 
-    for (; grp < ngroups; grp += gstride) {
+    auto layer = [&]<bool I>(const float* im, int ln, const f4 (&xx)[NT][HT], f4 (&yy)[NT][HT],
+                             float (&ss)[NT]) __attribute__((always_inline)) {
+        if constexpr (SKEW && NT == 2)
+            coupling_tile_skewed<H, L, I>(LdsOperands<H, L>(im, ln), xx, yy, ss);
+        else
+            coupling_tile<H, L, I, NT>(LdsOperands<H, L>(im, ln), xx, yy, ss);
+    };
+
+    for (;;) {
+        int nxt_off = 0;
+        if (lane == 0) nxt_off = atomicAdd(qhead, 1);
+        const int64_t nxt = g_lo + __builtin_amdgcn_readfirstlane(nxt_off);
+        const bool has_next = nxt < g_hi;
         f4 lo[NT][HT], hi[NT][HT];
         float ssum[NT];
 #pragma unroll
@@ -110,10 +133,10 @@ flow_fused_kernel(FlowFusedArgs a) {
                 hi[t][mm] = nhi[t][mm];
             }
         }
-        if (grp + gstride < ngroups) {
+        if (has_next) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                int64_t nrow = ((grp + gstride) * NT + t) * 16 + s;
+                int64_t nrow = (nxt * NT + t) * 16 + s;
                 if (nrow >= a.N) nrow = a.N - 1;
                 const float* zr = zb + nrow * D + 4 * q;
 #pragma unroll
@@ -129,17 +152,17 @@ flow_fused_kernel(FlowFusedArgs a) {
             for (int st = a.S - 1; st >= 0; --st) {
                 const int c1 = 2 * st + 1, c0 = 2 * st;
                 apply_fold<H, NT>(fold + c1 * 2 * D, q, lo, hi);  // Affine^-1, BN^-1
-                coupling_tile<H, L, true, NT>(LdsOperands<H, L>(img + c1 * Img::FLOATS, lane), hi, lo, ssum);
+                layer.template operator()<true>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
                 apply_fold<H, NT>(fold + c0 * 2 * D, q, lo, hi);  // BN^-1
-                coupling_tile<H, L, true, NT>(LdsOperands<H, L>(img + c0 * Img::FLOATS, lane), lo, hi, ssum);
+                layer.template operator()<true>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
             }
         } else {
             // density_estimator.py:375-387
             for (int st = 0; st < a.S; ++st) {
                 const int c0 = 2 * st, c1 = 2 * st + 1;
-                coupling_tile<H, L, false, NT>(LdsOperands<H, L>(img + c0 * Img::FLOATS, lane), lo, hi, ssum);
+                layer.template operator()<false>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
                 apply_fold<H, NT>(fold + c0 * 2 * D, q, lo, hi);  // BN
-                coupling_tile<H, L, false, NT>(LdsOperands<H, L>(img + c1 * Img::FLOATS, lane), hi, lo, ssum);
+                layer.template operator()<false>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
                 apply_fold<H, NT>(fold + c1 * 2 * D, q, lo, hi);  // BN, Affine
             }
         }
@@ -148,7 +171,7 @@ flow_fused_kernel(FlowFusedArgs a) {
         for (int t = 0; t < NT; ++t) {
             const int64_t row = (grp * NT + t) * 16 + s;
             const bool row_ok = row < a.N;
-            const float ld_tot = reduce_q(ssum[t]) + ldc;
+            const float ld_tot = __builtin_fmaf(reduce_q(ssum[t]), kLn2, ldc);  // the tile code sums s*log2(e)
             if (INV && lpo) {
                 float sq = 0.f;
 #pragma unroll
@@ -172,22 +195,35 @@ flow_fused_kernel(FlowFusedArgs a) {
                 }
             }
         }
+        if (!has_next) break;
+        grp = nxt;
     }
+#if TNF_STAMP
+    if ((blockIdx.x % 37) == 0 && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 7)) {
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - st_t0, dr = r1 - st_r0;
+        printf("stamp block %3d wave %d: entry %llu loopstart %llu end %llu (x10ns, mod 1e6) loop %.1f us clk %.3f GHz\n",
+               (int)blockIdx.x, wave, st_e0 % 1000000ull, st_r0 % 1000000ull, r1 % 1000000ull, dr * 0.01,
+               (double)dt / (double)dr * 0.1);
+    }
+#endif
 }
 
-constexpr int kFlowNT = 2;
-constexpr int kFlowWaves = 8;
+// (tiles per wave iteration, waves per workgroup) variants; index = g_flow_variant
+// (TNF_OPT_FLOW_VARIANT, a tuning hook).  One workgroup per CU (LDS-limited), so the
+// waves-per-workgroup choice IS the occupancy choice: 8 -> 2 waves/SIMD ... 16 -> 4.
+int g_flow_variant = 0;
 
 template <int H, int L>
 static size_t flow_lds_bytes(int S) {
-    return (size_t)2 * S * (LdsLayerImage<H, L>::FLOATS + 2 * 2 * H) * sizeof(float);
+    return (size_t)2 * S * (LdsLayerImage<H, L>::FLOATS + 2 * 2 * H) * sizeof(float) + 16;  // + queue head
 }
 
 static size_t flow_lds_bytes_rt(int D, int S, int L) {
     const int H = D / 2;
     const int HT = (H + 15) / 16;
     const int floats = (4 * HT + 2 * (L - 1)) * 256 + (2 + 2 * (L - 1) + 2 * HT) * 16;
-    return (size_t)2 * S * (floats + 2 * D) * sizeof(float);
+    return (size_t)2 * S * (floats + 2 * D) * sizeof(float) + 16;
 }
 
 bool flow_fused_supported(int D, int S, int L, int U) {
@@ -196,41 +232,54 @@ bool flow_fused_supported(int D, int S, int L, int U) {
     return flow_lds_bytes_rt(D, S, L) <= 160 * 1024;
 }
 
-template <int H, int L, bool INV>
-static int launch_t(const FlowFusedArgs& a, dim3 grid, hipStream_t st) {
+template <int H, int L, bool INV, int NT, int NW, bool SKEW = false>
+static int launch_t(const FlowFusedArgs& a, int64_t M, hipStream_t st) {
     const size_t smem = flow_lds_bytes<H, L>(a.S);
-    auto kern = flow_fused_kernel<H, L, INV, kFlowNT, kFlowWaves>;
+    auto kern = flow_fused_kernel<H, L, INV, NT, NW, SKEW>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_fused: cannot reserve %zu B of LDS", smem);
-    hipLaunchKernelGGL(kern, grid, dim3(kFlowWaves * 64), smem, st, a);
+    const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
+    int64_t bx = (ngroups + NW - 1) / NW;
+    int64_t cap = (256 + M - 1) / M;  // one workgroup per CU (LDS-limited), persistent over its groups
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)bx, (unsigned)M), dim3(NW * 64), smem, st, a);
     return TNF_OK;
 }
 
+template <int H, int L, bool INV>
+static int launch_v(const FlowFusedArgs& a, int64_t M, hipStream_t st) {
+    if (L == 2) {
+        switch (g_flow_variant) {
+            case 1: return launch_t<H, L, INV, 1, 8>(a, M, st);
+            case 2: return launch_t<H, L, INV, 1, 12>(a, M, st);
+            case 3: return launch_t<H, L, INV, 1, 16>(a, M, st);
+            case 4: return launch_t<H, L, INV, 2, 12>(a, M, st);
+            case 5: return launch_t<H, L, INV, 2, 8, true>(a, M, st);
+            default: break;
+        }
+    }
+    return launch_t<H, L, INV, 2, 8>(a, M, st);
+}
+
 template <int H>
-static int launch_h(const FlowFusedArgs& a, int L, int inverse, dim3 grid, hipStream_t st) {
+static int launch_h(const FlowFusedArgs& a, int L, int inverse, int64_t M, hipStream_t st) {
     switch (L) {
-        case 1: return inverse ? launch_t<H, 1, true>(a, grid, st) : launch_t<H, 1, false>(a, grid, st);
-        case 2: return inverse ? launch_t<H, 2, true>(a, grid, st) : launch_t<H, 2, false>(a, grid, st);
-        default: return inverse ? launch_t<H, 3, true>(a, grid, st) : launch_t<H, 3, false>(a, grid, st);
+        case 1: return inverse ? launch_v<H, 1, true>(a, M, st) : launch_v<H, 1, false>(a, M, st);
+        case 2: return inverse ? launch_v<H, 2, true>(a, M, st) : launch_v<H, 2, false>(a, M, st);
+        default: return inverse ? launch_v<H, 3, true>(a, M, st) : launch_v<H, 3, false>(a, M, st);
     }
 }
 
-int launch_flow_fused(const float* z, const float* params, const float* fold, const float* ldc,
+int launch_flow_fused(const float* z, const float* images, const float* fold, const float* ldc,
                       float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
-                      int64_t N, int D, int S, int L, int U, int64_t pstride, int inverse,
-                      hipStream_t st) {
+                      int64_t N, int D, int S, int L, int U, int inverse, hipStream_t st) {
     if (!flow_fused_supported(D, S, L, U))
         return fail(TNF_EUNSUPPORTED, "flow_fused: no kernel for D=%d S=%d L=%d U=%d", D, S, L, U);
     const int64_t M = Mz > Mp ? Mz : Mp;
     if (M > 65535) return fail(TNF_EUNSUPPORTED, "flow_fused: M=%lld too large", (long long)M);
     if (N <= 0) return TNF_OK;
-    FlowFusedArgs a{z, params, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, pstride, S, U};
-    const int64_t ngroups = (N + 16 * kFlowNT - 1) / (16 * kFlowNT);
-    int64_t bx = (ngroups + kFlowWaves - 1) / kFlowWaves;
-    int64_t cap = (256 + M - 1) / M;  // one 512-thread workgroup per CU (LDS-limited)
-    if (bx > cap) bx = cap;
-    dim3 grid((unsigned)bx, (unsigned)M);
-    int rc = (D == 64) ? launch_h<32>(a, L, inverse, grid, st) : launch_h<16>(a, L, inverse, grid, st);
+    FlowFusedArgs a{z, images, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, S, U};
+    int rc = (D == 64) ? launch_h<32>(a, L, inverse, M, st) : launch_h<16>(a, L, inverse, M, st);
     if (rc != TNF_OK) return rc;
     return check_launch("flow_fused");
 }

@@ -1,4 +1,4 @@
-// MFMA formulation of one RealNVP coupling layer on a 16-sample tile (gfx950).
+// MFMA formulation of one RealNVP coupling layer on 16-sample tiles (gfx950).
 //
 // Mapping (v_mfma_f32_16x16x4_f32, exact fp32 == k-ordered fmaf chain):
 //   lane l = (s, q), s = l & 15 (sample inside the tile), q = l >> 4.
@@ -17,10 +17,28 @@
 //   scale-shift happens in registers on the same lanes.
 //   log|det J| = sum_f s_f : 8 in-lane adds + two cross-lane adds (q = 0..3).
 //
-// Hidden width U <= 16 is zero-padded to 16 (padded units see weight 0 / bias 0,
-// tanh(0) = 0 exactly, and feed weight-0 columns).
+// Hidden width U <= 16 is zero-padded to 16 (padded units see weight 0 / bias 0).
+//
+// Activation folding (all done once, when the operands are built):
+//   tanh(a) = 1 - 2 r,  r = 1/(2^(c a) + 1),  c = 2 log2(e).
+//   * every layer that feeds a tanh has its weights and biases pre-multiplied by c,
+//     so the accumulator is already the exp2 argument;
+//   * the layer AFTER a tanh consumes r instead of tanh:  W.(1 - 2r) + b
+//     = (b + colsum(W)) + (-2W).r, so "1 - 2r" never executes;
+//   * the s-net's output layer is additionally scaled by log2(e): the kernel gets
+//     s' = s log2(e), uses exp2(+-s') directly and sums s'; the caller multiplies the
+//     reduced sum by ln 2.
+//   Per tanh that leaves v_exp_f32, v_add_f32, v_rcp_f32; per transformed feature
+//   v_sub/v_exp/v_mul (+ the log-det add).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#ifndef TNF_ABLATE
+#define TNF_ABLATE 0
+#endif
+#ifndef TNF_SKEW_SCHED
+#define TNF_SKEW_SCHED 0
+#endif
 
 namespace tnf {
 
@@ -30,38 +48,45 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// exp(x) = 2^(x*log2e) with the rounding error of the product fed back:
-// t = rn(x*L), d = fma(x, L, -t) + x*L_lo  ->  2^t * (1 + d*ln2).  v_exp_f32 is ~1 ulp.
-__device__ __forceinline__ float fast_exp(float x) {
-    const float L_hi = 1.44269502162933349609375f;   // rn(log2(e))
-    const float L_lo = 1.925963033500011e-08f;       // log2(e) - L_hi
-    const float t = x * L_hi;
-    const float d = __builtin_fmaf(x, L_hi, -t) + x * L_lo;
-    const float e = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(e * d, 0.693147182464599609375f, e);
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kTwoLog2e = 2.88539008177792681472f;
+constexpr float kLn2 = 0.69314718055994530942f;
+
+// r = 1/(2^a + 1)  (a = 2 log2(e) x  ->  tanh(x) = 1 - 2r).  2^a -> inf gives r = 0, -> 0 gives r = 1.
+__device__ __forceinline__ float sig2(float a) {
+#if TNF_ABLATE == 1
+    return a;  // timing experiment only: no transcendental work
+#else
+    return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a) + 1.0f);
+#endif
 }
 
-// tanh(x) = sign(x) * (1 - 2/(exp(2|x|) + 1)); abs error <= ~1.5e-7, exact 0 at 0,
-// saturates cleanly (exp -> inf -> 2/inf = 0).
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float ax = __builtin_fabsf(x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777926815f);  // 2*log2(e)
-    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
-    const float t = __builtin_fmaf(-2.0f, r, 1.0f);
-    return __builtin_copysignf(t, x);
-}
-
-__device__ __forceinline__ f4 tanh4(f4 v) {
+__device__ __forceinline__ f4 sig2_4(f4 v) {
     f4 r;
-    r[0] = fast_tanh(v[0]);
-    r[1] = fast_tanh(v[1]);
-    r[2] = fast_tanh(v[2]);
-    r[3] = fast_tanh(v[3]);
+    r[0] = sig2(v[0]);
+    r[1] = sig2(v[1]);
+    r[2] = sig2(v[2]);
+    r[3] = sig2(v[3]);
     return r;
 }
 
+// sum over the four q-lanes that share a sample / an operand row (lanes r, r+16, r+32, r+48)
+__device__ __forceinline__ float reduce_q(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// Unconditional load + select: a predicated `ok ? p[i] : 0` makes hipcc branch around every
+// load and drain vmcnt per element (a chain of dependent L2 round trips); this form keeps
+// all loads of the gather in flight together.
+__device__ __forceinline__ float ld_sel(const float* __restrict__ p, int idx, bool ok) {
+    const float v = p[ok ? idx : 0];
+    return ok ? v : 0.f;
+}
+
 // Per-lane MFMA operands of one coupling layer (weights = A operands, biases =
-// accumulator initial values).  H = half width (d_in = d_out), L = num_layers.
+// accumulator initial values), already folded as described above.
 template <int H, int L>
 struct LayerW {
     static constexpr int HT = (H + 15) / 16;
@@ -76,13 +101,14 @@ struct LayerW {
 
 // Gather the operands of lane (r = lane&15, q = lane>>4) from the reference's packed
 // parameter row (bijectors.py:222-235): per MLP layer [W_t | W_s | b_t | b_s], W[in][out].
+// Must be called by a full wave (the column sums use cross-lane shuffles).
 template <int H, int L>
 __device__ __forceinline__ void load_layer_w(LayerW<H, L>& w, const float* __restrict__ p, int U,
                                              int lane) {
     constexpr int HT = LayerW<H, L>::HT;
     const int r = lane & 15, q = lane >> 4;
     const bool r_ok = r < U;
-    // layer 0: H -> U
+    // layer 0: H -> U, feeds a tanh: scale by c
     {
         const float* wt = p;
         const float* ws = p + H * U;
@@ -94,54 +120,79 @@ __device__ __forceinline__ void load_layer_w(LayerW<H, L>& w, const float* __res
             for (int j = 0; j < 4; ++j) {
                 const int f = 16 * m + 4 * q + j;
                 const bool ok = r_ok && f < H;
-                w.w0[0][m * 4 + j] = ok ? wt[f * U + r] : 0.f;
-                w.w0[1][m * 4 + j] = ok ? ws[f * U + r] : 0.f;
+                w.w0[0][m * 4 + j] = kTwoLog2e * ld_sel(wt, f * U + r, ok);
+                w.w0[1][m * 4 + j] = kTwoLog2e * ld_sel(ws, f * U + r, ok);
             }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int u = 4 * q + j;
-            w.b0[0][j] = u < U ? bt[u] : 0.f;
-            w.b0[1][j] = u < U ? bs[u] : 0.f;
+            w.b0[0][j] = kTwoLog2e * ld_sel(bt, u, u < U);
+            w.b0[1][j] = kTwoLog2e * ld_sel(bs, u, u < U);
         }
         p = bs + U;
     }
-    // hidden layers: U -> U
+    // hidden layers: U -> U, consume r, feed a tanh
 #pragma unroll
     for (int l = 0; l < L - 1; ++l) {
         const float* wt = p;
         const float* ws = p + U * U;
         const float* bt = p + 2 * U * U;
         const float* bs = bt + U;
+        float ct = 0.f, cs = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = 4 * q + j;
             const bool ok = r_ok && k < U;
-            w.wh[l][0][j] = ok ? wt[k * U + r] : 0.f;
-            w.wh[l][1][j] = ok ? ws[k * U + r] : 0.f;
-            w.bh[l][0][j] = k < U ? bt[k] : 0.f;
-            w.bh[l][1][j] = k < U ? bs[k] : 0.f;
+            const float a = ld_sel(wt, k * U + r, ok);
+            const float b = ld_sel(ws, k * U + r, ok);
+            ct += a;
+            cs += b;
+            w.wh[l][0][j] = -2.f * kTwoLog2e * a;
+            w.wh[l][1][j] = -2.f * kTwoLog2e * b;
+        }
+        ct = reduce_q(ct);  // column sum of W_t for output unit r
+        cs = reduce_q(cs);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = 4 * q + j;
+            const float st = __shfl(ct, u), ss = __shfl(cs, u);
+            w.bh[l][0][j] = u < U ? kTwoLog2e * (ld_sel(bt, u, u < U) + st) : 0.f;
+            w.bh[l][1][j] = u < U ? kTwoLog2e * (ld_sel(bs, u, u < U) + ss) : 0.f;
         }
         p = bs + U;
     }
-    // output layer: U -> H
+    // output layer: U -> H, consumes r; t plain, s scaled by log2(e)
     {
         const float* wt = p;
         const float* ws = p + U * H;
         const float* bt = p + 2 * U * H;
         const float* bs = bt + H;
 #pragma unroll
-        for (int mo = 0; mo < HT; ++mo)
+        for (int mo = 0; mo < HT; ++mo) {
+            float ct = 0.f, cs = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 4 * q + j;
                 const int o = 16 * mo + r;
                 const bool ok = k < U && o < H;
-                w.w2[0][mo][j] = ok ? wt[k * H + o] : 0.f;
-                w.w2[1][mo][j] = ok ? ws[k * H + o] : 0.f;
-                const int ob = 16 * mo + 4 * q + j;
-                w.b2[0][mo][j] = ob < H ? bt[ob] : 0.f;
-                w.b2[1][mo][j] = ob < H ? bs[ob] : 0.f;
+                const float a = ld_sel(wt, k * H + o, ok);
+                const float b = ld_sel(ws, k * H + o, ok);
+                ct += a;
+                cs += b;
+                w.w2[0][mo][j] = -2.f * a;
+                w.w2[1][mo][j] = -2.f * kLog2e * b;
             }
+            ct = reduce_q(ct);  // column sum for output feature 16mo + r
+            cs = reduce_q(cs);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = 4 * q + j;  // row inside the 16-feature tile held by this lane
+                const int ob = 16 * mo + rr;
+                const float st = __shfl(ct, rr), ss = __shfl(cs, rr);
+                w.b2[0][mo][j] = ob < H ? ld_sel(bt, ob, ob < H) + st : 0.f;
+                w.b2[1][mo][j] = ob < H ? kLog2e * (ld_sel(bs, ob, ob < H) + ss) : 0.f;
+            }
+        }
     }
 }
 
@@ -241,12 +292,12 @@ __device__ __forceinline__ void store_layer_image(float* img, const LayerW<H, L>
 // One coupling layer on NT tiles that share the layer's operands (independent MFMA
 // chains -> the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 is covered).
 // x = conditioner half (unchanged), y = transformed half (updated in place),
-// ssum[t] += this lane's share of sum(s).
+// ssum2[t] += this lane's share of sum(s)*log2(e)  (multiply the total by ln 2).
 //   forward : y = t + y*exp(s)     (bijectors.py:172)
-//   inverse : y = (y - t)/exp(s)   (bijectors.py:198), evaluated as (y - t)*exp(-s)
+//   inverse : y = (y - t)/exp(s)   (bijectors.py:198), evaluated as (y - t)*2^(-s')
 template <int H, int L, bool INV, int NT, class OP>
 __device__ __forceinline__ void coupling_tile(const OP& op, const f4 (&x)[NT][(H + 15) / 16],
-                                              f4 (&y)[NT][(H + 15) / 16], float (&ssum)[NT]) {
+                                              f4 (&y)[NT][(H + 15) / 16], float (&ssum2)[NT]) {
     constexpr int HT = (H + 15) / 16;
     f4 at[NT], as[NT];
     {
@@ -270,8 +321,8 @@ __device__ __forceinline__ void coupling_tile(const OP& op, const f4 (&x)[NT][(H
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        at[t] = tanh4(at[t]);
-        as[t] = tanh4(as[t]);
+        at[t] = sig2_4(at[t]);
+        as[t] = sig2_4(as[t]);
     }
 #pragma unroll
     for (int l = 0; l < L - 1; ++l) {
@@ -292,8 +343,8 @@ __device__ __forceinline__ void coupling_tile(const OP& op, const f4 (&x)[NT][(H
             }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            at[t] = tanh4(nt[t]);
-            as[t] = tanh4(ns[t]);
+            at[t] = sig2_4(nt[t]);
+            as[t] = sig2_4(ns[t]);
         }
     }
 #pragma unroll
@@ -317,21 +368,139 @@ __device__ __forceinline__ void coupling_tile(const OP& op, const f4 (&x)[NT][(H
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float s1 = sv[t][j];
-                ssum[t] += s1;
+                const float s2 = sv[t][j];
+                ssum2[t] += s2;
+#if TNF_ABLATE == 1
                 if (INV)
-                    y[t][mo][j] = (y[t][mo][j] - tt[t][j]) * fast_exp(-s1);
+                    y[t][mo][j] = (y[t][mo][j] - tt[t][j]) * s2;
+#else
+                if (INV)
+                    y[t][mo][j] = (y[t][mo][j] - tt[t][j]) * __builtin_amdgcn_exp2f(-s2);
+#endif
                 else
-                    y[t][mo][j] = __builtin_fmaf(y[t][mo][j], fast_exp(s1), tt[t][j]);
+                    y[t][mo][j] = __builtin_fmaf(y[t][mo][j], __builtin_amdgcn_exp2f(s2), tt[t][j]);
             }
     }
 }
 
-// sum over the four q-lanes that share a sample (lanes s, s+16, s+32, s+48)
-__device__ __forceinline__ float reduce_q(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+// ---------------------------------------------------------------------------
+// Two-tile software pipeline of one coupling layer (whole-flow kernel, MFMA-bound).
+// A tile's layer is the stage chain  S0 V0 [S1 V1 ...] S2 V2  where the S stages are
+// MFMA chains and the V stages the VALU work that depends on them (sigmoids, the
+// scale-shift).  Running both tiles in lock-step leaves the matrix pipe idle during
+// every V stage; here tile B lags tile A by one stage, so each bracket pairs one tile's
+// MFMAs with the other tile's VALU work, and sched_group_barrier pins the interleave.
+// ---------------------------------------------------------------------------
+template <int H>
+struct TileRegs {
+    static constexpr int HT = (H + 15) / 16;
+    f4 at, as;
+    f4 tt[HT], sv[HT];
+};
+
+template <int K, int H, int L, bool INV, class OP>
+__device__ __forceinline__ void run_stage(const OP& op, TileRegs<H>& r, const f4 (&x)[(H + 15) / 16],
+                                          f4 (&y)[(H + 15) / 16], float& ssum2) {
+    constexpr int HT = (H + 15) / 16;
+    if constexpr (K == 0) {  // S0: H -> U
+        r.at = op.b0(0);
+        r.as = op.b0(1);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) {
+            const f4 wt = op.w0(0, m), ws = op.w0(1, m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r.at = mfma4(wt[j], x[m][j], r.at);
+                r.as = mfma4(ws[j], x[m][j], r.as);
+            }
+        }
+    } else if constexpr (K < 2 * L && (K & 1)) {  // V: r = 1/(2^acc + 1)
+        r.at = sig2_4(r.at);
+        r.as = sig2_4(r.as);
+    } else if constexpr (K < 2 * L) {  // hidden layer l = K/2 - 1: U -> U
+        constexpr int l = K / 2 - 1;
+        const f4 wt = op.wh(l, 0), ws = op.wh(l, 1);
+        f4 nt = op.bh(l, 0), ns = op.bh(l, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            nt = mfma4(wt[j], r.at[j], nt);
+            ns = mfma4(ws[j], r.as[j], ns);
+        }
+        r.at = nt;
+        r.as = ns;
+    } else if constexpr (K == 2 * L) {  // S2: U -> H
+#pragma unroll
+        for (int mo = 0; mo < HT; ++mo) {
+            r.tt[mo] = op.b2(0, mo);
+            r.sv[mo] = op.b2(1, mo);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mo = 0; mo < HT; ++mo) {
+                r.tt[mo] = mfma4(op.w2(0, mo)[j], r.at[j], r.tt[mo]);
+                r.sv[mo] = mfma4(op.w2(1, mo)[j], r.as[j], r.sv[mo]);
+            }
+    } else {  // V2: scale-shift + log-det share
+#pragma unroll
+        for (int mo = 0; mo < HT; ++mo)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float s2 = r.sv[mo][j];
+                ssum2 += s2;
+                if (INV)
+                    y[mo][j] = (y[mo][j] - r.tt[mo][j]) * __builtin_amdgcn_exp2f(-s2);
+                else
+                    y[mo][j] = __builtin_fmaf(y[mo][j], __builtin_amdgcn_exp2f(s2), r.tt[mo][j]);
+            }
+    }
+}
+
+template <int NM, int NV>
+__device__ __forceinline__ void interleave_mfma_valu() {
+    // NM MFMAs, each followed by NV VALU instructions, in program order
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  // VALU
+    }
+}
+
+template <int I, int H, int L, bool INV, class OP>
+__device__ __forceinline__ void skew_bracket(const OP& op, TileRegs<H>& ra, TileRegs<H>& rb,
+                                             const f4 (&xa)[(H + 15) / 16], f4 (&ya)[(H + 15) / 16],
+                                             const f4 (&xb)[(H + 15) / 16], f4 (&yb)[(H + 15) / 16],
+                                             float& sa, float& sb) {
+    constexpr int HT = (H + 15) / 16;
+    constexpr int NS = 2 * L + 2;
+    if constexpr (I <= NS) {
+        if constexpr (I < NS) run_stage<I, H, L, INV>(op, ra, xa, ya, sa);
+        if constexpr (I >= 1) run_stage<I - 1, H, L, INV>(op, rb, xb, yb, sb);
+        // which stream holds the MFMAs in this bracket, and how many
+        constexpr int KM = (I & 1) ? I - 1 : I;  // the even (MFMA) stage index present
+        constexpr bool has_m = (I & 1) ? true : (I < NS);
+        constexpr int NM = !has_m ? 0 : (KM == 0 ? 8 * HT : (KM == 2 * L ? 8 * HT : 8));
+        constexpr int KV = (I & 1) ? I : I - 1;  // the odd (VALU) stage index present
+        constexpr bool has_v = (I & 1) ? (I < NS) : (I >= 1);
+        constexpr int NVt = !has_v ? 0 : (KV == 2 * L + 1 ? 4 * 4 * HT : 24);
+#if TNF_SKEW_SCHED == 2
+        if constexpr (NM > 0 && NVt > 0) interleave_mfma_valu<NM, (NVt + NM - 1) / NM>();
+        __builtin_amdgcn_sched_barrier(0);
+#elif TNF_SKEW_SCHED == 1
+        __builtin_amdgcn_sched_barrier(0);
+#elif TNF_SKEW_SCHED == 3
+        if constexpr (NM > 0 && NVt > 0) interleave_mfma_valu<NM, (NVt + NM - 1) / NM>();
+#endif
+        skew_bracket<I + 1, H, L, INV>(op, ra, rb, xa, ya, xb, yb, sa, sb);
+    }
+}
+
+// One coupling layer on two tiles, tile B one stage behind tile A.
+template <int H, int L, bool INV, class OP>
+__device__ __forceinline__ void coupling_tile_skewed(const OP& op, const f4 (&x)[2][(H + 15) / 16],
+                                                     f4 (&y)[2][(H + 15) / 16], float (&ssum2)[2]) {
+    TileRegs<H> ra, rb;
+    skew_bracket<0, H, L, INV>(op, ra, rb, x[0], y[0], x[1], y[1], ssum2[0], ssum2[1]);
 }
 
 }  // namespace tnf

@@ -53,6 +53,8 @@ __host__ __device__ inline FlowLayout flow_layout(int D, int S, int L, int U) {
 
 // ---- runtime options (testing hooks) ---------------------------------------
 extern int g_force_generic;
+extern int g_flow_variant;   // flow_fused.hip
+extern int g_layer_variant;  // coupling_mfma.hip
 
 // ---- kernels implemented in the .hip files ----------------------------------
 int launch_coupling_generic(int dtype, const void* z, const void* params, void* z_out,
@@ -68,6 +70,8 @@ struct MfmaLayerArgs {
     float* z_out;  // may be NULL when finalising
     const float* params;
     int64_t pstride;
+    const float* image;  // optional prepared operand image (per m: image_stride floats); else gather from params
+    int64_t image_stride;
     const float* pre;
     const float* post;
     int64_t fold_stride;
@@ -82,15 +86,16 @@ struct MfmaLayerArgs {
 };
 int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st);
 
-// fold BN/Affine constants for the flow-level chains. fold: (Mp, 2S, 2, D), ldc: (Mp)
-int launch_flow_fold(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
-                     float* ldc, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
-                     int inverse, hipStream_t st);
+// Per-call preparation for the flow-level chains: fold BN/Affine constants (fold: (Mp, 2S, 2, D),
+// ldc: (Mp)) and build the lane-ordered MFMA operand images (Mp, 2S, mfma_image_floats(D, L)).
+int64_t mfma_image_floats(int D, int L);
+int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
+                     float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
+                     int64_t pstride, int inverse, hipStream_t st);
 
-int launch_flow_fused(const float* z, const float* params, const float* fold, const float* ldc,
+int launch_flow_fused(const float* z, const float* images, const float* fold, const float* ldc,
                       float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
-                      int64_t N, int D, int S, int L, int U, int64_t pstride, int inverse,
-                      hipStream_t st);
+                      int64_t N, int D, int S, int L, int U, int inverse, hipStream_t st);
 bool flow_fused_supported(int D, int S, int L, int U);
 
 int launch_affine(int dtype, const void* z, const void* params, void* z_out, void* log_det,
@@ -100,6 +105,16 @@ int launch_bn_apply(int dtype, const void* z, const float* mean, const float* al
                     float* log_det, int64_t rows, int D, int inverse, hipStream_t st);
 int launch_bn_batch_forward(const float* z, float* z_out, float* mean_out, float* alpha_out,
                             float* log_det, int64_t rows, int D, float eps, void* ws, hipStream_t st);
+
+int launch_coupling_backward(int dtype, const void* z, const void* params, const void* g_zout,
+                             const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp,
+                             int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
+                             int64_t gpstride, hipStream_t st);
+int launch_affine_backward(int dtype, const void* z, const void* params, const void* g_zout,
+                           const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N,
+                           int D, int inverse, int64_t pstride, int64_t gpstride, hipStream_t st);
+int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, void* g_z, int64_t rows,
+                             int D, int inverse, hipStream_t st);
 
 int launch_base_log_density(const double* omega, double* out, int64_t rows, int D, hipStream_t st);
 

@@ -1,19 +1,83 @@
-"""Backward passes of the bijector kernels (autograd hooks of ops.py)."""
+"""Backward passes of the bijector kernels (the autograd hooks of ops.py).
+
+Each function calls one HIP backward kernel through the C ABI (tnf_*_backward); the
+activations are recomputed inside the kernel from the saved layer input, so autograd keeps
+only z and the parameters alive.  Parameter gradients are reduced over the samples with
+float atomics in the kernel.
+"""
+import torch
+
+from . import _lib
+from ._lib import lib, check
 
 
-def _todo(what):
-    raise NotImplementedError(
-        "torch_nf_amd: the HIP backward kernel for %s is not built yet; run under torch.no_grad() "
-        "(there is deliberately no PyTorch fallback)." % what)
+def _dev(t, dev):
+    return t if t.device == dev else t.to(dev)
 
 
 def coupling_backward(z, params, z_out, g_z, g_ld, D, L, U, upper, inverse):
-    _todo("RealNVP")
+    dev = _lib.require_device()
+    home_z, home_p = z.device, params.device
+    code = _lib.F32 if z.dtype == torch.float32 else _lib.F64
+    zc = _dev(z.detach(), dev).contiguous()
+    pc = _dev(params.detach(), dev)
+    if pc.stride(1) != 1:
+        pc = pc.contiguous()
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = max(Mz, Mp)
+    if Mz != M:  # broadcast z explicitly; its gradient is summed back over m below
+        zc = zc.expand(M, N, D).contiguous()
+    g_zo = torch.zeros((M, N, D), dtype=z.dtype, device=dev) if g_z is None else _dev(g_z, dev).contiguous()
+    g_l = torch.zeros((M, N), dtype=z.dtype, device=dev) if g_ld is None else _dev(g_ld, dev).contiguous()
+    gz = torch.empty((M, N, D), dtype=z.dtype, device=dev)
+    gp = torch.zeros(tuple(params.shape), dtype=params.dtype, device=dev)
+    pstride = pc.stride(0) if Mp > 1 else max(pc.stride(0), pc.shape[1])
+    if N > 0:
+        check(lib.tnf_coupling_backward(code, zc.data_ptr(), pc.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
+                                        gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, L, U, int(upper), int(inverse),
+                                        pstride, gp.shape[1], _lib.stream_ptr()))
+    if Mz != M:
+        gz = gz.sum(0, keepdim=True)
+    return (gz if home_z == dev else gz.to(home_z)), (gp if home_p == dev else gp.to(home_p))
 
 
 def affine_backward(z, params, z_out, g_z, g_ld, D, inverse):
-    _todo("Affine")
+    dev = _lib.require_device()
+    home_z, home_p = z.device, params.device
+    code = _lib.F32 if z.dtype == torch.float32 else _lib.F64
+    zc = _dev(z.detach(), dev).contiguous()
+    pc = _dev(params.detach(), dev)
+    if pc.stride(1) != 1:
+        pc = pc.contiguous()
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = max(Mz, Mp)
+    if Mz != M:
+        zc = zc.expand(M, N, D).contiguous()
+    g_zo = torch.zeros((M, N, D), dtype=z.dtype, device=dev) if g_z is None else _dev(g_z, dev).contiguous()
+    g_l = torch.zeros((Mp, 1), dtype=z.dtype, device=dev) if g_ld is None else _dev(g_ld, dev).contiguous()
+    gz = torch.empty((M, N, D), dtype=z.dtype, device=dev)
+    gp = torch.zeros(tuple(params.shape), dtype=params.dtype, device=dev)
+    pstride = pc.stride(0) if Mp > 1 else max(pc.stride(0), pc.shape[1])
+    check(lib.tnf_affine_backward(code, zc.data_ptr(), pc.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
+                                  gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, int(inverse), pstride, gp.shape[1],
+                                  _lib.stream_ptr()))
+    if Mz != M:
+        gz = gz.sum(0, keepdim=True)
+    return (gz if home_z == dev else gz.to(home_z)), (gp if home_p == dev else gp.to(home_p))
 
 
 def bn_apply_backward(g_z, alpha, inverse):
-    _todo("BatchNorm")
+    if g_z is None:
+        return None
+    dev = _lib.require_device()
+    home = g_z.device
+    code = _lib.F32 if g_z.dtype == torch.float32 else _lib.F64
+    gc = _dev(g_z, dev).contiguous()
+    ac = _dev(alpha.detach().float(), dev).contiguous()
+    out = torch.empty_like(gc)
+    D = gc.shape[-1]
+    check(lib.tnf_bn_apply_backward(code, gc.data_ptr(), ac.data_ptr(), out.data_ptr(), gc.numel() // D, D,
+                                    int(inverse), _lib.stream_ptr()))
+    return out if home == dev else out.to(home)
