@@ -41,6 +41,17 @@ def _force_generic(tnf, on):
     tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FORCE_GENERIC, int(on)))
 
 
+DEFAULT_FLOW_VARIANT = 10  # split-f16 whole-flow kernel; 0 = the fp32-MFMA whole-flow kernel
+
+
+@pytest.fixture(params=[10, 0], ids=["wholeflow_f16split", "wholeflow_f32mfma"])
+def flow_variant(request, tnf):
+    """Run a test once per whole-flow kernel implementation (both sit behind TNF_FUSE_FLOW)."""
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FLOW_VARIANT, request.param))
+    yield request.param
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FLOW_VARIANT, DEFAULT_FLOW_VARIANT))
+
+
 # --------------------------------------------------------------------------
 # 1. golden vectors
 # --------------------------------------------------------------------------
@@ -111,7 +122,7 @@ def _install_stats(nf, mean, alpha):
 
 
 @pytest.mark.parametrize("fusion", ["auto", "layer", "flow", "bijectors"])
-def test_golden_flow(tnf, fusion):
+def test_golden_flow(tnf, fusion, flow_variant):
     g = load_golden("flow")
     L_ = tnf._lib
     for ci in range(len(g["meta"])):
@@ -195,7 +206,7 @@ def _rand_flow(tnf, D, S, L, U, seed, sigma=0.1, M=1):
 @pytest.mark.parametrize("D,S,L,U,N", [(64, 4, 2, 15, 16384), (32, 4, 2, 15, 16384), (64, 1, 1, 16, 1000),
                                        (32, 2, 3, 15, 4097), (64, 4, 2, 15, 31), (2, 1, 2, 15, 1024),
                                        (6, 2, 2, 20, 513)])
-def test_oracle_log_prob(tnf, oracle, D, S, L, U, N):
+def test_oracle_log_prob(tnf, oracle, flow_variant, D, S, L, U, N):
     nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=N + D)
     z = torch.randn(1, N, D, generator=torch.Generator().manual_seed(1))
     want = oracle.flow_log_prob(z, params, D, S, L, U, stats)
@@ -207,7 +218,7 @@ def test_oracle_log_prob(tnf, oracle, D, S, L, U, N):
         torch.testing.assert_close(got.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
 
 
-def test_oracle_many_contexts(tnf, oracle):
+def test_oracle_many_contexts(tnf, oracle, flow_variant):
     """M_p = M_z > 1 (per-context weights, cfg 3 shape family) and M_p = 1 broadcast."""
     D, S, L, U = 64, 4, 2, 15
     for M, N in [(16, 512), (3, 40), (64, 1), (5, 17)]:
@@ -259,7 +270,7 @@ def test_host_tensors_are_staged(tnf, oracle):
 # 3. properties at the benchmark size
 # --------------------------------------------------------------------------
 @pytest.mark.parametrize("D", [64, 32])
-def test_full_size_properties(tnf, oracle, D):
+def test_full_size_properties(tnf, oracle, flow_variant, D):
     S, L, U, N = 4, 2, 15, 1 << 20
     nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=11)
     params = params.cuda()
@@ -311,7 +322,7 @@ def test_full_size_layer_roundtrip(tnf):
     torch.testing.assert_close(ldi, ldf, rtol=1e-5, atol=1e-6)
 
 
-def test_edge_shapes(tnf, oracle):
+def test_edge_shapes(tnf, oracle, flow_variant):
     """Ragged / tiny inputs: N below one MFMA tile, N = 1, tails that are not a multiple of 16 or 32."""
     D, S, L, U = 64, 4, 2, 15
     nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=21)

@@ -25,10 +25,12 @@ alpha = np.exp(rng.normal(0.0, 0.2, (2 * S, D))).astype(np.float32)
 for b, m, a in zip(nf._bn_layers(), mean, alpha):
     b.set_last_stats(torch.from_numpy(m).cuda(), torch.from_numpy(a).cuda())
 stats = [(torch.from_numpy(m), torch.from_numpy(a)) for m, a in zip(mean, alpha)]
-fv = int(os.environ.get("TNF_FLOW_VARIANT", "0"))
-lv = int(os.environ.get("TNF_LAYER_VARIANT", "0"))
-tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FLOW_VARIANT, fv))
-tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_LAYER_VARIANT, lv))
+fv = int(os.environ.get("TNF_FLOW_VARIANT", "-1"))
+lv = int(os.environ.get("TNF_LAYER_VARIANT", "-1"))
+if fv >= 0:
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FLOW_VARIANT, fv))
+if lv >= 0:
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_LAYER_VARIANT, lv))
 z = torch.randn(1, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
 want = orc.flow_log_prob(z[:, :8192].cpu(), params, D, S, L, U, stats)
 for name, fusion in (("flow ", tnf._lib.FUSE_FLOW), ("layer", tnf._lib.FUSE_LAYER)):

@@ -200,6 +200,7 @@ class BatchNorm(Bijector):
         self.eps = eps
         self._last_mean = torch.tensor(np.zeros(D)).float()
         self._last_alpha = torch.tensor(np.ones(D)).float()
+        self._version = 0  # bumped whenever the cached statistics change (NormFlow caches the stacked copy)
 
     def get_last_mean(self):
         return self._last_mean
@@ -211,6 +212,7 @@ class BatchNorm(Bijector):
         """Install cached statistics (e.g. restored from a checkpoint or all-reduced)."""
         self._last_mean = mean.detach().float()
         self._last_alpha = alpha.detach().float()
+        self._version += 1
 
     def __call__(self, z, use_last=False):
         return self.forward_and_log_det(z, use_last=use_last)
@@ -220,6 +222,7 @@ class BatchNorm(Bijector):
             return ops.bn_apply(z, self._last_mean, self._last_alpha, False)
         z_norm, log_det, mean, alpha = ops.bn_batch_forward(z, self.eps)
         self._last_mean, self._last_alpha = mean, alpha
+        self._version += 1
         return z_norm, log_det
 
     def inverse_and_log_det(self, z):

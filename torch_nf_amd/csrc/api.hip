@@ -280,6 +280,12 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
     const int64_t img_floats = mfma_image_floats(D, L);
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 1, st);
     if (rc) return rc;
+    if (use_fused && g_flow_variant >= 10) {
+        rc = launch_flow_images_f16(params, images, M_p, D, S, L, U, pstride, st);
+        if (rc) return rc;
+        return launch_flow_fused_f16(z, images, fold, ldc, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U,
+                                     1, g_flow_variant, st);
+    }
     if (use_fused)
         return launch_flow_fused(z, images, fold, ldc, z0, sum_log_det, log_prob, M_z, M_p, N, D, S,
                                  L, U, 1, st);
@@ -339,6 +345,12 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
     const int64_t img_floats = mfma_image_floats(D, L);
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 0, st);
     if (rc) return rc;
+    if (use_fused && g_flow_variant >= 10) {
+        rc = launch_flow_images_f16(params, images, M_p, D, S, L, U, pstride, st);
+        if (rc) return rc;
+        return launch_flow_fused_f16(omega, images, fold, ldc, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L,
+                                     U, 0, g_flow_variant, st);
+    }
     if (use_fused)
         return launch_flow_fused(omega, images, fold, ldc, z_out, sum_log_det, nullptr, M_z, M_p, N,
                                  D, S, L, U, 0, st);

@@ -97,6 +97,12 @@ int launch_flow_fused(const float* z, const float* images, const float* fold, co
                       float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
                       int64_t N, int D, int S, int L, int U, int inverse, hipStream_t st);
 bool flow_fused_supported(int D, int S, int L, int U);
+// split-f16 variant of the whole-flow kernel (flow_fused_f16.hip); images in slots of mfma_image_floats(D, 3)
+int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,
+                           int64_t pstride, hipStream_t st);
+int launch_flow_fused_f16(const float* z, const float* images, const float* fold, const float* ldc,
+                          float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
+                          int64_t N, int D, int S, int L, int U, int inverse, int variant, hipStream_t st);
 
 int launch_affine(int dtype, const void* z, const void* params, void* z_out, void* log_det,
                   int64_t Mz, int64_t Mp, int64_t N, int D, int inverse, int64_t pstride,

@@ -160,10 +160,17 @@ class NormFlow(DensityEstimator):
         return [b for b in self.bijectors if b.name == "BatchNorm"]
 
     def _bn_stats(self, dev):
+        """(2S, D) stacks of the cached BatchNorm statistics on `dev`; rebuilt only when a
+        BatchNorm layer's statistics changed (keeps the per-call host work off the hot path)."""
         bns = self._bn_layers()
-        mean = torch.stack([b.get_last_mean().detach().float().to(dev) for b in bns])
-        alpha = torch.stack([b.get_last_alpha().detach().float().to(dev) for b in bns])
-        return mean, alpha
+        key = (dev, tuple(b._version for b in bns))
+        cached = self.__dict__.get("_bn_cache")
+        if cached is None or cached[0] != key:
+            mean = torch.stack([b.get_last_mean().detach().float().to(dev) for b in bns])
+            alpha = torch.stack([b.get_last_alpha().detach().float().to(dev) for b in bns])
+            cached = (key, mean, alpha)
+            self.__dict__["_bn_cache"] = cached
+        return cached[1], cached[2]
 
     def _fused_ok(self, z, params):
         """One-call fused path: coupling stack, float32, no autograd, MFMA-covered shape."""

@@ -28,6 +28,13 @@ def _stage(t, dev):
     return t.contiguous()
 
 
+def _stats(t, dev):
+    """BatchNorm statistics as contiguous float32 on the device (no-op when they already are)."""
+    if t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad:
+        return t
+    return _stage(t.detach().float(), dev)
+
+
 def _rows(params, dev):
     """(M_p, P) parameter rows with unit inner stride -> (tensor, row_stride)."""
     if params.dim() != 2:
@@ -279,8 +286,8 @@ def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE
         raise TypeError("the fused flow kernels are float32")
     zc = _stage(z, dev)
     pc, pstride = _rows(params, dev)
-    mean_c = _stage(bn_mean.detach().float(), dev)
-    alpha_c = _stage(bn_alpha.detach().float(), dev)
+    mean_c = _stats(bn_mean, dev)
+    alpha_c = _stats(bn_alpha, dev)
     Mz, N = zc.shape[0], zc.shape[1]
     Mp = pc.shape[0]
     M = _bcast_M(Mz, Mp)
@@ -313,8 +320,8 @@ def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.F
         raise TypeError("the fused flow kernels are float32")
     oc = _stage(omega, dev)
     pc, pstride = _rows(params, dev)
-    mean_c = _stage(bn_mean.detach().float(), dev)
-    alpha_c = _stage(bn_alpha.detach().float(), dev)
+    mean_c = _stats(bn_mean, dev)
+    alpha_c = _stats(bn_alpha, dev)
     Mz, N = oc.shape[0], oc.shape[1]
     Mp = pc.shape[0]
     M = _bcast_M(Mz, Mp)
