@@ -184,6 +184,11 @@ int tnf_coupling_backward(int32_t dtype, const void* z, const void* params, cons
     if (!z || !params || !g_z_out || !g_log_det || !g_z || !g_params)
         return fail(TNF_EINVAL, "tnf_coupling_backward: NULL pointer");
     if (N == 0) return TNF_OK;
+    if (dtype == TNF_F32 && !g_force_generic && mfma_supported(D, L, U) && N >= 16 && aligned16(z) &&
+        aligned16(g_z_out) && aligned16(g_z))
+        return launch_coupling_backward_mfma((const float*)z, (const float*)params, (const float*)g_z_out,
+                                             (const float*)g_log_det, (float*)g_z, (float*)g_params, M, M_p, N,
+                                             D, L, U, upper, inverse, pstride, gpstride, as_stream(stream));
     return launch_coupling_backward(dtype, z, params, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
                                     upper, inverse, pstride, gpstride, as_stream(stream));
 }

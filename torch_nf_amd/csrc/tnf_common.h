@@ -116,6 +116,10 @@ int launch_coupling_backward(int dtype, const void* z, const void* params, const
                              const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp,
                              int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
                              int64_t gpstride, hipStream_t st);
+int launch_coupling_backward_mfma(const float* z, const float* params, const float* g_zout,
+                                  const float* g_ld, float* g_z, float* g_params, int64_t M, int64_t Mp,
+                                  int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
+                                  int64_t gpstride, hipStream_t st);
 int launch_affine_backward(int dtype, const void* z, const void* params, const void* g_zout,
                            const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N,
                            int D, int inverse, int64_t pstride, int64_t gpstride, hipStream_t st);
