@@ -348,3 +348,36 @@ def test_errors_are_loud(tnf):
         layer(z, torch.zeros(3, layer.count_num_params(), device="cuda"))
     with pytest.raises(TypeError):
         layer(z.half(), torch.zeros(2, layer.count_num_params(), device="cuda").half())
+
+
+def test_many_contexts_beyond_grid_y(tnf, oracle):
+    """M > 65,535 parameter rows (gridDim.y alone would overflow) with N = 1: the SNPE layout
+    cde.log_prob(z[:, None, :], x) of the reference's training loops (notebooks/LFI_learning_rules.ipynb:304)."""
+    D, S, L, U, M = 4, 1, 2, 15, 70001
+    rng = np.random.RandomState(5)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    params = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float()
+    mean = rng.normal(0, 0.3, (2 * S, D)).astype(np.float32)
+    alpha = np.exp(rng.normal(0, 0.2, (2 * S, D))).astype(np.float32)
+    _install_stats(nf, mean, alpha)
+    stats = [(torch.from_numpy(m), torch.from_numpy(a)) for m, a in zip(mean, alpha)]
+    z = torch.tensor(rng.normal(0, 1, (M, 1, D))).float()
+    with torch.no_grad():
+        got = nf.log_prob(z.cuda(), params.cuda()).cpu()
+    sel = torch.cat([torch.arange(0, 300), torch.arange(65400, 65700), torch.arange(M - 300, M)])
+    want = oracle.flow_log_prob(z[sel], params[sel], D, S, L, U, stats)
+    torch.testing.assert_close(got[sel], want, rtol=LOGP_RTOL, atol=1e-5)
+    # and the MFMA shapes: D = 64 with per-context weights, few samples each (per-bijector path)
+    D, S = 64, 4
+    M = 300
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    params = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float()
+    mean = rng.normal(0, 0.3, (2 * S, D)).astype(np.float32)
+    alpha = np.exp(rng.normal(0, 0.2, (2 * S, D))).astype(np.float32)
+    _install_stats(nf, mean, alpha)
+    stats = [(torch.from_numpy(m), torch.from_numpy(a)) for m, a in zip(mean, alpha)]
+    for N in (1, 20):
+        z = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+        with torch.no_grad():
+            got = nf.log_prob(z.cuda(), params.cuda()).cpu()
+        torch.testing.assert_close(got, oracle.flow_log_prob(z, params, D, S, L, U, stats), rtol=LOGP_RTOL, atol=1e-5)

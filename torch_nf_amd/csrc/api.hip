@@ -110,8 +110,9 @@ int tnf_coupling(int32_t dtype, const void* z, const void* params, void* z_out, 
     if (z == z_out) return fail(TNF_EINVAL, "tnf_coupling: z_out must not alias z");
     if (N == 0) return TNF_OK;
     hipStream_t st = as_stream(stream);
-    if (dtype == TNF_F32 && !g_force_generic && mfma_supported(D, L, U) && N >= 16 && aligned16(z) &&
-        aligned16(z_out)) {
+    const int64_t Mmax = M_z > M_p ? M_z : M_p;
+    if (dtype == TNF_F32 && !g_force_generic && mfma_supported(D, L, U) && (N >= 16 || Mmax >= 8) &&
+        aligned16(z) && aligned16(z_out)) {
         MfmaLayerArgs a;
         memset(&a, 0, sizeof(a));
         a.z = (const float*)z;

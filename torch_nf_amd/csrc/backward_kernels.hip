@@ -37,13 +37,14 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 coupling_backward_kernel(const T* __restrict__ z, const T* __restrict__ params,
                          const T* __restrict__ g_zout, const T* __restrict__ g_ld,
-                         T* __restrict__ g_z, T* __restrict__ g_params, int64_t Mp, int64_t N, int D,
-                         int L, int U, int upper, int inverse, int64_t pstride, int64_t gpstride,
+                         T* __restrict__ g_z, T* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N,
+                         int D, int L, int U, int upper, int inverse, int64_t pstride, int64_t gpstride,
                          int TS, int W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= M) return;
     const int64_t n0 = (int64_t)blockIdx.x * TS;
     const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
     const int h = D / 2;
@@ -220,20 +221,19 @@ int launch_coupling_backward(int dtype, const void* z, const void* params, const
     if (smem > 160 * 1024)
         return fail(TNF_EUNSUPPORTED, "coupling_backward: layer width %d needs %zu B of LDS", W, smem);
     const int64_t tiles = (N + TS - 1) / TS;
-    if (tiles > 0x7fffffff || M > 65535)
-        return fail(TNF_EUNSUPPORTED, "coupling_backward: grid too large");
-    dim3 grid((unsigned)tiles, (unsigned)M);
+    if (tiles > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "coupling_backward: grid too large");
+    const dim3 grid = grid_xm(tiles, M);
     if (dtype == TNF_F32) {
         auto k = coupling_backward_kernel<float>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const float*)z, (const float*)params,
-                           (const float*)g_zout, (const float*)g_ld, (float*)g_z, (float*)g_params, Mp, N, D,
+                           (const float*)g_zout, (const float*)g_ld, (float*)g_z, (float*)g_params, M, Mp, N, D,
                            L, U, upper, inverse, pstride, gpstride, (int)TS, W);
     } else {
         auto k = coupling_backward_kernel<double>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const double*)z, (const double*)params,
-                           (const double*)g_zout, (const double*)g_ld, (double*)g_z, (double*)g_params, Mp,
+                           (const double*)g_zout, (const double*)g_ld, (double*)g_z, (double*)g_params, M, Mp,
                            N, D, L, U, upper, inverse, pstride, gpstride, (int)TS, W);
     }
     return check_launch("coupling_backward");
@@ -249,12 +249,13 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 affine_backward_kernel(const T* __restrict__ z, const T* __restrict__ params,
                        const T* __restrict__ g_zout, const T* __restrict__ g_ld, T* __restrict__ g_z,
-                       T* __restrict__ g_params, int64_t Mp, int64_t N, int D, int inverse,
+                       T* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N, int D, int inverse,
                        int64_t pstride, int64_t gpstride, int64_t rows_per_block) {
     __shared__ double red_a[256];
     __shared__ double red_b[256];
     const int tid = threadIdx.x;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= M) return;
     const int64_t mp = Mp == 1 ? 0 : m;
     const T* p = params + mp * pstride;
     T* gp = g_params + mp * gpstride;
@@ -314,19 +315,19 @@ int launch_affine_backward(int dtype, const void* z, const void* params, const v
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     const int64_t rpb = (N + blocks - 1) / blocks;
-    dim3 grid((unsigned)blocks, (unsigned)M);
+    const dim3 grid = grid_xm(blocks, M);
     if (dtype == TNF_F32) {
         if (N > 0)
             hipLaunchKernelGGL(affine_backward_kernel<float>, grid, dim3(256), 0, st, (const float*)z,
                                (const float*)params, (const float*)g_zout, (const float*)g_ld, (float*)g_z,
-                               (float*)g_params, Mp, N, D, inverse, pstride, gpstride, rpb);
+                               (float*)g_params, M, Mp, N, D, inverse, pstride, gpstride, rpb);
         hipLaunchKernelGGL(affine_backward_ld_kernel<float>, dim3((unsigned)Mp), dim3(256), 0, st,
                            (const float*)g_ld, (float*)g_params, D, gpstride);
     } else {
         if (N > 0)
             hipLaunchKernelGGL(affine_backward_kernel<double>, grid, dim3(256), 0, st, (const double*)z,
                                (const double*)params, (const double*)g_zout, (const double*)g_ld,
-                               (double*)g_z, (double*)g_params, Mp, N, D, inverse, pstride, gpstride, rpb);
+                               (double*)g_z, (double*)g_params, M, Mp, N, D, inverse, pstride, gpstride, rpb);
         hipLaunchKernelGGL(affine_backward_ld_kernel<double>, dim3((unsigned)Mp), dim3(256), 0, st,
                            (const double*)g_ld, (double*)g_params, D, gpstride);
     }

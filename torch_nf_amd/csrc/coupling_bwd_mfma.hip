@@ -142,7 +142,8 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= a.M) return;
     const int64_t mp = a.Mp == 1 ? 0 : m;
     const float* prow = a.params + mp * a.pstride;
     float* scrA = lds + FImg::FLOATS + BImg::FLOATS + wave * 2 * SCR;
@@ -431,14 +432,13 @@ int launch_coupling_backward_mfma(const float* z, const float* params, const flo
                                   int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
                                   int64_t gpstride, hipStream_t st) {
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "coupling_backward_mfma: D=%d L=%d U=%d", D, L, U);
-    if (M > 65535) return fail(TNF_EUNSUPPORTED, "coupling_backward_mfma: M=%lld too large", (long long)M);
     BwdArgs a{z, params, g_zout, g_ld, g_z, g_params, M, Mp, N, pstride, gpstride, U, upper};
     const int64_t ntiles = (N + 15) / 16;
     int64_t bx = (ntiles + 3) / 4;
     int64_t cap = 512 / M;  // persistent grid (2 workgroups per CU): each ends with one atomic per parameter
     if (cap < 1) cap = 1;
     if (bx > cap) bx = cap;
-    dim3 grid((unsigned)bx, (unsigned)M);
+    const dim3 grid = grid_xm(bx, M);
     if (D == 64) {
         if (L == 1) launch_bwd_hl<32, 1>(a, inverse, grid, st);
         else if (L == 2) launch_bwd_hl<32, 2>(a, inverse, grid, st);

@@ -71,10 +71,11 @@ flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_
 template <int H, int L>
 __global__ void __launch_bounds__(64)
 flow_images_kernel(const float* __restrict__ params, float* __restrict__ images, int S, int U,
-                   int64_t pstride, int64_t image_floats) {
+                   int64_t pstride, int64_t image_floats, int64_t Mp) {
     constexpr int D = 2 * H;
     const int c = blockIdx.x;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= Mp) return;
     const int64_t pc = coupling_num_params(D, L, U, 1);
     const int64_t stage = 2 * pc + 2 * D;
     LayerW<H, L> w;
@@ -92,10 +93,10 @@ int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_
                      int64_t pstride, int inverse, hipStream_t st) {
     hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
                        bn_alpha, fold, ldc, D, S, L, U, pstride, inverse);
-    const dim3 grid((unsigned)(2 * S), (unsigned)Mp);
+    const dim3 grid = grid_xm(2 * S, Mp);
     const int64_t fl = mfma_image_floats(D, L);
 #define TNF_IMG(HH, LL) \
-    hipLaunchKernelGGL((flow_images_kernel<HH, LL>), grid, dim3(64), 0, st, params, images, S, U, pstride, fl)
+    hipLaunchKernelGGL((flow_images_kernel<HH, LL>), grid, dim3(64), 0, st, params, images, S, U, pstride, fl, Mp)
     if (D == 64) {
         if (L == 1) TNF_IMG(32, 1); else if (L == 2) TNF_IMG(32, 2); else TNF_IMG(32, 3);
     } else {
@@ -121,7 +122,16 @@ coupling_mfma_kernel(MfmaLayerArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
-    const int64_t m = blockIdx.y;
+    // workgroup per context (default) or, for many contexts with a handful of samples each
+    // (SNPE-style N = 1 calls), one context per wave: every wave gathers its own operands anyway
+    const int64_t Mtot = a.Mz > a.Mp ? a.Mz : a.Mp;
+    int64_t m = a.wave_m ? (int64_t)blockIdx.x * 4 + wave : grid_m();
+    const bool m_ok = m < Mtot;
+    if (!m_ok) {
+        if (!a.wave_m) return;  // whole workgroup out of range
+        m = Mtot - 1;           // keep the wave alive for the barrier below; it gets no samples
+    }
+    const int64_t Nv = m_ok ? a.N : 0;
     const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
 
     const bool has_pre = a.pre != nullptr, has_post = a.post != nullptr;
@@ -177,9 +187,9 @@ coupling_mfma_kernel(MfmaLayerArgs a) {
     const float ldc = a.ldc ? a.ldc[mp] : 0.f;
 
     // a "group" = NT consecutive 16-sample tiles handled by one wave per iteration
-    const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
-    const int64_t gstride = (int64_t)gridDim.x * 4;
-    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t ngroups = (Nv + 16 * NT - 1) / (16 * NT);
+    const int64_t gstride = a.wave_m ? 1 : (int64_t)gridDim.x * 4;
+    int64_t grp = a.wave_m ? 0 : (int64_t)blockIdx.x * 4 + wave;
     if (grp >= ngroups) return;
 
     f4 nx[NT][HT], ny[NT][HT];
@@ -311,11 +321,18 @@ int g_layer_variant = 0;
 template <int H, int L, bool INV, int NT, bool LDSOP>
 static void launch_k(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {
     const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
+    if (!LDSOP && !a.pre && !a.post && !a.image && M >= 8 && ngroups <= 2) {
+        MfmaLayerArgs b = a;
+        b.wave_m = 1;
+        hipLaunchKernelGGL((coupling_mfma_kernel<H, L, INV, NT, LDSOP>), dim3((unsigned)((M + 3) / 4)), dim3(256),
+                           0, st, b);
+        return;
+    }
     int64_t bx = (ngroups + 3) / 4;
     int64_t cap = 2048 / M;
     if (cap < 1) cap = 1;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL((coupling_mfma_kernel<H, L, INV, NT, LDSOP>), dim3((unsigned)bx, (unsigned)M), dim3(256),
+    hipLaunchKernelGGL((coupling_mfma_kernel<H, L, INV, NT, LDSOP>), grid_xm(bx, M), dim3(256),
                        0, st, a);
 }
 
@@ -341,7 +358,6 @@ int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st) {
     if (!mfma_supported(a.D, a.L, a.U))
         return fail(TNF_EUNSUPPORTED, "coupling_mfma: no kernel for D=%d L=%d U=%d", a.D, a.L, a.U);
     const int64_t M = a.Mz > a.Mp ? a.Mz : a.Mp;
-    if (M > 65535) return fail(TNF_EUNSUPPORTED, "coupling_mfma: M=%lld too large", (long long)M);
     if (a.N <= 0) return TNF_OK;
     if (a.D == 64) launch_h<32>(a, M, st);
     else launch_h<16>(a, M, st);

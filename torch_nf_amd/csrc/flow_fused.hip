@@ -60,7 +60,8 @@ flow_fused_kernel(FlowFusedArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= (a.Mz > a.Mp ? a.Mz : a.Mp)) return;
     const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
 #if TNF_STAMP
     const unsigned long long st_e0 = __builtin_amdgcn_s_memrealtime();
@@ -242,7 +243,7 @@ static int launch_t(const FlowFusedArgs& a, int64_t M, hipStream_t st) {
     int64_t bx = (ngroups + NW - 1) / NW;
     int64_t cap = (256 + M - 1) / M;  // one workgroup per CU (LDS-limited), persistent over its groups
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(kern, dim3((unsigned)bx, (unsigned)M), dim3(NW * 64), smem, st, a);
+    hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(NW * 64), smem, st, a);
     return TNF_OK;
 }
 
@@ -276,7 +277,6 @@ int launch_flow_fused(const float* z, const float* images, const float* fold, co
     if (!flow_fused_supported(D, S, L, U))
         return fail(TNF_EUNSUPPORTED, "flow_fused: no kernel for D=%d S=%d L=%d U=%d", D, S, L, U);
     const int64_t M = Mz > Mp ? Mz : Mp;
-    if (M > 65535) return fail(TNF_EUNSUPPORTED, "flow_fused: M=%lld too large", (long long)M);
     if (N <= 0) return TNF_OK;
     FlowFusedArgs a{z, images, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, S, U};
     int rc = (D == 64) ? launch_h<32>(a, L, inverse, M, st) : launch_h<16>(a, L, inverse, M, st);

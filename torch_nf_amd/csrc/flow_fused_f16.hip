@@ -98,13 +98,14 @@ static_assert(F16Image<16, 3>::FLOATS <= LdsLayerImage<16, 3>::FLOATS, "f16 imag
 template <int H, int L>
 __global__ void __launch_bounds__(64)
 flow_images_f16_kernel(const float* __restrict__ params, float* __restrict__ images, int S, int U,
-                       int64_t pstride, int64_t image_floats) {
+                       int64_t pstride, int64_t image_floats, int64_t Mp) {
     constexpr int D = 2 * H;
     typedef F16Image<H, L> Img;
     constexpr int HT = Img::HT;
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= Mp) return;
     const int64_t pc = coupling_num_params(D, L, U, 1);
     const int64_t stage = 2 * pc + 2 * D;
     LayerW<H, L> w;
@@ -331,7 +332,8 @@ flow_fused_f16_kernel(FlowF16Args a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= (a.Mz > a.Mp ? a.Mz : a.Mp)) return;
     const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
     {
         for (int c = 0; c < nl; ++c) {
@@ -452,8 +454,8 @@ flow_fused_f16_kernel(FlowF16Args a) {
 template <int H, int L>
 static void launch_images16(const float* params, float* images, int64_t Mp, int S, int U, int64_t pstride,
                             int64_t slot, hipStream_t st) {
-    hipLaunchKernelGGL((flow_images_f16_kernel<H, L>), dim3((unsigned)(2 * S), (unsigned)Mp), dim3(64), 0, st,
-                       params, images, S, U, pstride, slot);
+    hipLaunchKernelGGL((flow_images_f16_kernel<H, L>), grid_xm(2 * S, Mp), dim3(64), 0, st,
+                       params, images, S, U, pstride, slot, Mp);
 }
 
 int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,
@@ -481,7 +483,7 @@ static int launch16_t(const FlowF16Args& a, int64_t M, hipStream_t st) {
     int64_t bx = (ngroups + NW - 1) / NW;
     int64_t cap = (256 + M - 1) / M;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(kern, dim3((unsigned)bx, (unsigned)M), dim3(NW * 64), smem, st, a);
+    hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(NW * 64), smem, st, a);
     return TNF_OK;
 }
 
@@ -509,7 +511,6 @@ int launch_flow_fused_f16(const float* z, const float* images, const float* fold
                           int64_t N, int D, int S, int L, int U, int inverse, int variant, hipStream_t st) {
     (void)U;
     const int64_t M = Mz > Mp ? Mz : Mp;
-    if (M > 65535) return fail(TNF_EUNSUPPORTED, "flow_fused_f16: M=%lld too large", (long long)M);
     if (N <= 0) return TNF_OK;
     FlowF16Args a{z, images, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, mfma_image_floats(D, 3), S};
     int rc = (D == 64) ? launch16_h<32>(a, L, inverse, M, variant, st) : launch16_h<16>(a, L, inverse, M, variant, st);

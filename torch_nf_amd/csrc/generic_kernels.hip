@@ -32,7 +32,8 @@ coupling_generic_kernel(const T* __restrict__ z, const T* __restrict__ params, T
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* buf = reinterpret_cast<T*>(smem_raw);  // [net][pingpong][TS][W]
     const int tid = threadIdx.x;
-    const int64_t m = blockIdx.y;
+    const int64_t m = grid_m();
+    if (m >= (Mz > Mp ? Mz : Mp)) return;
     const int64_t n0 = (int64_t)blockIdx.x * TS;
     const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
     const int h = D / 2;
@@ -121,9 +122,9 @@ int launch_coupling_generic(int dtype, const void* z, const void* params, void* 
     const size_t smem = (size_t)4 * TS * W * esz;
     if (smem > 160 * 1024) return fail(TNF_EUNSUPPORTED, "coupling: layer width %d needs %zu B of LDS", W, smem);
     const int64_t tiles = (N + TS - 1) / TS;
-    if (tiles > 0x7fffffff || M > 65535)
+    if (tiles > 0x7fffffff)
         return fail(TNF_EUNSUPPORTED, "coupling: grid too large (tiles=%lld, M=%lld)", (long long)tiles, (long long)M);
-    dim3 grid((unsigned)tiles, (unsigned)M);
+    const dim3 grid = grid_xm(tiles, M);
     if (dtype == TNF_F32) {
         if (smem > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)coupling_generic_kernel<float>,

@@ -16,6 +16,17 @@ int check_launch(const char* what);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// The batch index m (parameter row / context) rides on grid dimensions y and z so that any M
+// works (gridDim.y alone stops at 65,535 -- SNPE-style calls have 10^5..10^6 contexts).
+inline dim3 grid_xm(int64_t bx, int64_t M) {
+    const int64_t my = M < 32768 ? M : 32768;
+    const int64_t mz = (M + my - 1) / my;
+    return dim3((unsigned)bx, (unsigned)my, (unsigned)mz);
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t grid_m() { return (int64_t)blockIdx.y + (int64_t)gridDim.y * (int64_t)blockIdx.z; }
+#endif
+
 // ---- packed parameter layout of one RealNVP layer (bijectors.py:222-242) ---
 // [W_t (d_in*d_out, row-major [in][out]) | W_s | b_t (d_out) | b_s (d_out)] per MLP layer,
 // layers: d_in0 -> U, (U -> U) x (L-1), U -> d_out.
@@ -83,6 +94,7 @@ struct MfmaLayerArgs {
     int add_ldc;  // add ldc[m] into ld_out as well
     int64_t Mz, Mp, N;
     int D, L, U, upper, inverse;
+    int wave_m;  // set by the launcher: one context (m) per wave instead of per workgroup (many contexts, few samples)
 };
 int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st);
 

@@ -180,6 +180,10 @@ class NormFlow(DensityEstimator):
             return False
         if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
             return False
+        # per-context weights with very few samples each (the SNPE layout, N = 1): the prepared
+        # operand images (~100 KB per context) would outweigh the samples; compose per bijector
+        if params.size(0) > 1 and z.size(1) < 32:
+            return False
         return ops.has_fast_path(self.D, self.num_layers, self.num_units)
 
     # -- sampling -----------------------------------------------------------
@@ -198,10 +202,15 @@ class NormFlow(DensityEstimator):
         return self._forward_from(omega, params, freeze_bn)
 
     def _forward_from(self, omega, params, freeze_bn=False):
-        """`forward` with the base draw injected (numpy float64 (M,N,D))."""
+        """`forward` with the base draw injected: numpy float64 (M,N,D) like the reference's host
+        draw, or a torch tensor (e.g. a device-side torch.randn draw, which skips the host RNG and
+        the 8 B/value PCIe copy)."""
         home = params.device
         dev = _lib.require_device()
-        omega64 = torch.as_tensor(np.ascontiguousarray(omega), dtype=torch.float64).to(dev)
+        if torch.is_tensor(omega):
+            omega64 = omega.detach().to(device=dev, dtype=torch.float64)
+        else:
+            omega64 = torch.as_tensor(np.ascontiguousarray(omega), dtype=torch.float64).to(dev)
         z = omega64.float()
         log_q = ops.base_log_density_f64(omega64)
         p_dev = params if params.device == dev else params.to(dev)
