@@ -142,8 +142,10 @@ int tnf_bn_apply_backward(int32_t dtype, const void* g_z_out, const float* alpha
 
 /* Base density of NormFlow.forward, float64 like the reference's numpy expression
  * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as
- * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)).  omega (rows, D) float64 -> out (rows) float64. */
-int tnf_base_log_density_f64(const double* omega, double* out, int64_t rows, int32_t D, void* stream);
+ * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)) in float64.  omega (rows, D) of `dtype` (TNF_F64 for
+ * the reference's host draw, TNF_F32 for a device-side draw) -> out (rows) float64. */
+int tnf_base_log_density_f64(int32_t dtype, const void* omega, double* out, int64_t rows, int32_t D,
+                             void* stream);
 
 /* ---- flow level (arch_type "coupling", float32) ------------------------ */
 /* Stack per stage: RealNVP(upper), BN, RealNVP(lower), BN, Affine

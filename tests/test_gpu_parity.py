@@ -381,3 +381,39 @@ def test_many_contexts_beyond_grid_y(tnf, oracle):
         with torch.no_grad():
             got = nf.log_prob(z.cuda(), params.cuda()).cpu()
         torch.testing.assert_close(got, oracle.flow_log_prob(z, params, D, S, L, U, stats), rtol=LOGP_RTOL, atol=1e-5)
+
+
+def test_sample_uses_device_rng_and_matches_log_prob(tnf):
+    """NormFlow.sample (extension): device-side base draw; its log_q equals log_prob of its z."""
+    for D in (64, 6):
+        nf, params, stats = _rand_flow(tnf, D, 2, 2, 15, seed=31)
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        with torch.no_grad():
+            z, lq = nf.sample(5000, generator=gen)
+            lp = nf.log_prob(z)
+        assert z.shape == (1, 5000, D) and z.dtype == torch.float32 and lq.dtype == torch.float64
+        assert z.is_cuda and torch.isfinite(lq).all()
+        torch.testing.assert_close(lp.double(), lq, rtol=1e-4, atol=1e-3)
+        with torch.no_grad():
+            z2, _ = nf.sample(5000, generator=torch.Generator(device="cuda").manual_seed(3))
+        assert torch.equal(z, z2)  # same generator state -> same draw, same kernels -> same bits
+
+
+def test_hip_graph_capture(tnf, oracle):
+    """The C-ABI calls enqueue on torch's current stream and never synchronise or allocate, so a
+    log_prob call can be captured into a HIP graph and replayed on new data."""
+    D, S, L, U, N = 64, 4, 2, 15, 4096
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=41)
+    z_static = torch.randn(1, N, D, device="cuda")
+    with torch.no_grad():
+        nf.log_prob(z_static)  # warm-up: workspace allocation, BN-stat cache
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out_static = nf.log_prob(z_static)
+        z_new = torch.randn(1, N, D, generator=torch.Generator().manual_seed(9))
+        z_static.copy_(z_new)
+        g.replay()
+        torch.cuda.synchronize()
+    want = oracle.flow_log_prob(z_new, params, D, S, L, U, stats)
+    torch.testing.assert_close(out_static.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)

@@ -218,10 +218,12 @@ int tnf_bn_apply_backward(int32_t dtype, const void* g_z_out, const float* alpha
     return launch_bn_apply_backward(dtype, g_z_out, alpha, g_z, rows, D, inverse, as_stream(stream));
 }
 
-int tnf_base_log_density_f64(const double* omega, double* out, int64_t rows, int32_t D, void* stream) {
+int tnf_base_log_density_f64(int32_t dtype, const void* omega, double* out, int64_t rows, int32_t D,
+                             void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_base_log_density_f64: dtype %d", dtype);
     if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_base_log_density_f64: rows=%lld D=%d", (long long)rows, D);
     if (!omega || !out) return fail(TNF_EINVAL, "tnf_base_log_density_f64: NULL pointer");
-    return launch_base_log_density(omega, out, rows, D, as_stream(stream));
+    return launch_base_log_density(dtype, omega, out, rows, D, as_stream(stream));
 }
 
 int tnf_flow_fused_supported(int32_t D, int32_t S, int32_t L, int32_t U) {

@@ -351,21 +351,32 @@ int launch_bn_batch_forward(const float* z, float* z_out, float* mean_out, float
 // ---------------------------------------------------------------------------
 // Base Gaussian log-density in float64 (density_estimator.py:369-372).
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
-base_log_density_kernel(const double* __restrict__ omega, double* __restrict__ out, int64_t rows, int D) {
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
-        const double* w = omega + r * D;
+base_log_density_kernel(const T* __restrict__ omega, double* __restrict__ out, int64_t rows, int D) {
+    // 4 lanes per row: coalesced enough for the 256-B rows of D = 64 and exact in float64
+    const int sub = threadIdx.x & 3;
+    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; r < rows; r += ((int64_t)gridDim.x * 256) >> 2) {
+        const T* w = omega + r * D;
         double acc = 0.0;
-        for (int d = 0; d < D; ++d) acc += w[d] * w[d];
-        out[r] = -0.5 * acc - (double)D * 0.91893853320467274178;
+        for (int d = sub; d < D; d += 4) acc += (double)w[d] * (double)w[d];
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (sub == 0) out[r] = -0.5 * acc - (double)D * 0.91893853320467274178;
     }
 }
 
-int launch_base_log_density(const double* omega, double* out, int64_t rows, int D, hipStream_t st) {
-    int64_t blocks = (rows + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (rows > 0)
-        hipLaunchKernelGGL(base_log_density_kernel, dim3((unsigned)blocks), dim3(256), 0, st, omega, out, rows, D);
+int launch_base_log_density(int dtype, const void* omega, double* out, int64_t rows, int D, hipStream_t st) {
+    int64_t blocks = (rows * 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (rows > 0) {
+        if (dtype == TNF_F32)
+            hipLaunchKernelGGL(base_log_density_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st,
+                               (const float*)omega, out, rows, D);
+        else
+            hipLaunchKernelGGL(base_log_density_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st,
+                               (const double*)omega, out, rows, D);
+    }
     return check_launch("base_log_density");
 }
 

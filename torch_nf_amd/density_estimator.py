@@ -201,18 +201,32 @@ class NormFlow(DensityEstimator):
         omega = np.random.normal(0.0, 1.0, (M, N, self.D))
         return self._forward_from(omega, params, freeze_bn)
 
+    def sample(self, N=100, params=None, freeze_bn=True, generator=None):
+        """Extension (not in the reference): like `forward`, but the base draw comes from the
+        device RNG (`torch.randn` on the flow's device, optional `generator`), so no host RNG,
+        no float64 staging and no PCIe copy.  Not reproducible against np.random.seed."""
+        if not self.conditioner:
+            params = self.params
+        dev = _lib.require_device()
+        omega = torch.randn((params.size(0), N, self.D), device=dev, dtype=torch.float32, generator=generator)
+        return self._forward_from(omega, params, freeze_bn)
+
     def _forward_from(self, omega, params, freeze_bn=False):
         """`forward` with the base draw injected: numpy float64 (M,N,D) like the reference's host
         draw, or a torch tensor (e.g. a device-side torch.randn draw, which skips the host RNG and
         the 8 B/value PCIe copy)."""
         home = params.device
         dev = _lib.require_device()
-        if torch.is_tensor(omega):
-            omega64 = omega.detach().to(device=dev, dtype=torch.float64)
+        if torch.is_tensor(omega) and omega.dtype == torch.float32:
+            z = omega.detach().to(dev)  # device-side draw: no float64 round trip
+            log_q = ops.base_log_density_f64(z)
         else:
-            omega64 = torch.as_tensor(np.ascontiguousarray(omega), dtype=torch.float64).to(dev)
-        z = omega64.float()
-        log_q = ops.base_log_density_f64(omega64)
+            if torch.is_tensor(omega):
+                omega64 = omega.detach().to(device=dev, dtype=torch.float64)
+            else:
+                omega64 = torch.as_tensor(np.ascontiguousarray(omega), dtype=torch.float64).to(dev)
+            z = omega64.float()
+            log_q = ops.base_log_density_f64(omega64)
         p_dev = params if params.device == dev else params.to(dev)
 
         if freeze_bn and self._fused_ok(z, p_dev):

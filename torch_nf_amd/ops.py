@@ -238,13 +238,14 @@ def bn_batch_forward(z, eps):
 # base density (float64, like the reference's numpy expression)
 # ---------------------------------------------------------------------------
 def base_log_density_f64(omega):
-    """omega (M,N,D) float64 tensor -> (M,N) float64 log N(omega; 0, I)."""
+    """omega (M,N,D) float64 or float32 tensor -> (M,N) float64 log N(omega; 0, I)."""
     dev = _lib.require_device()
     home = omega.device
-    oc = _stage(omega.to(torch.float64), dev)
+    oc = _stage(omega, dev)
+    code = _dtype_code(oc)
     M, N, D = oc.shape
     out = torch.empty((M, N), dtype=torch.float64, device=dev)
-    check(lib.tnf_base_log_density_f64(oc.data_ptr(), out.data_ptr(), M * N, D, _lib.stream_ptr()))
+    check(lib.tnf_base_log_density_f64(code, oc.data_ptr(), out.data_ptr(), M * N, D, _lib.stream_ptr()))
     return out if home == dev else out.to(home)
 
 
