@@ -79,7 +79,9 @@ int64_t tnf_coupling_num_params(int32_t D, int32_t num_layers, int32_t num_units
 int64_t tnf_flow_num_params(int32_t D, int32_t num_stages, int32_t num_layers,
                             int32_t num_units);
 
-/* Returns 1 if (D, L, U) has an MFMA fast-path kernel in this build, else 0. */
+/* Returns 1 if (D, L, U) has an MFMA kernel in this build (the specialised D = 32 / 64,
+ * U <= 16, L <= 3 kernels, or the wide per-layer kernel: D % 8 == 0, D <= 128, U <= 64,
+ * L <= 5), else 0 (the generic kernels then run it). */
 int tnf_has_fast_path(int32_t D, int32_t num_layers, int32_t num_units);
 
 /* ---- bijector level -------------------------------------------------- */
@@ -151,7 +153,8 @@ int tnf_base_log_density_f64(int32_t dtype, const void* omega, double* out, int6
 /* Stack per stage: RealNVP(upper), BN, RealNVP(lower), BN, Affine
  * (density_estimator.py:260-270); bn_mean / bn_alpha are (2*S, D) float32 in
  * forward order.  Workspace size for either entry point: */
-int64_t tnf_flow_workspace_bytes(int64_t M, int64_t N, int32_t D, int32_t num_stages, int32_t fusion);
+int64_t tnf_flow_workspace_bytes(int64_t M, int64_t N, int32_t D, int32_t num_stages, int32_t num_layers,
+                                 int32_t num_units, int32_t fusion);
 
 /* Returns 1 if the whole-flow kernel (TNF_FUSE_FLOW) exists for this configuration
  * (MFMA fast path and all 2*S layers' operands fit the 160 KB of LDS), else 0. */

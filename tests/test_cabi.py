@@ -37,7 +37,8 @@ def test_version_and_counts(oracle):
                 assert lib.tnf_flow_num_params(D, 3, L, U) == oracle.flow_num_params(D, 3, L, U)
     assert lib.tnf_flow_num_params(64, 4, 2, 15) == 20464
     assert lib.tnf_has_fast_path(64, 2, 15) == 1 and lib.tnf_has_fast_path(32, 2, 15) == 1
-    assert lib.tnf_has_fast_path(5, 2, 15) == 0 and lib.tnf_has_fast_path(64, 2, 64) == 0
+    assert lib.tnf_has_fast_path(5, 2, 15) == 0 and lib.tnf_has_fast_path(64, 2, 65) == 0
+    assert lib.tnf_has_fast_path(64, 2, 64) == 1 and lib.tnf_has_fast_path(8, 5, 20) == 1  # wide per-layer kernel
     assert lib.tnf_flow_fused_supported(64, 4, 2, 15) == 1
     assert lib.tnf_flow_fused_supported(64, 40, 2, 15) == 0  # 80 layers of operands do not fit 160 KB of LDS
 
@@ -55,7 +56,7 @@ def test_argument_checks_return_codes_without_launching():
     assert rc == -1 and b"dtype" in lib.tnf_last_error()
     rc = lib.tnf_coupling(_lib.F32, dummy, dummy, None, dummy, 1, 1, 4, 8, 2, 15, 1, 0, 1000, 0, None)
     assert rc == -1 and b"NULL" in lib.tnf_last_error()
-    rc = lib.tnf_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, 1, 1, 4, 5, 1, 2, 15, 10000,
+    rc = lib.tnf_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, 1, 1, 4, 6, 1, 2, 15, 10000,
                                    0, dummy, 1 << 30, None)
     assert rc == _lib.EUNSUPPORTED and b"no fused kernel" in lib.tnf_last_error()
     rc = lib.tnf_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, 1, 1, 4, 64, 4, 2, 15, 20464,
@@ -67,5 +68,5 @@ def test_argument_checks_return_codes_without_launching():
         assert False
     except _lib.TnfError as e:
         assert e.code == -1
-    assert lib.tnf_flow_workspace_bytes(1, 1 << 20, 64, 4, _lib.FUSE_FLOW) < 1 << 18  # constants + operand images only
-    assert lib.tnf_flow_workspace_bytes(1, 1 << 20, 64, 4, _lib.FUSE_LAYER) > (1 << 20) * 64 * 4
+    assert lib.tnf_flow_workspace_bytes(1, 1 << 20, 64, 4, 2, 15, _lib.FUSE_FLOW) < 1 << 18  # constants + operand images only
+    assert lib.tnf_flow_workspace_bytes(1, 1 << 20, 64, 4, 2, 15, _lib.FUSE_LAYER) > (1 << 20) * 64 * 4

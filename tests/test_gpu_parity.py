@@ -131,6 +131,8 @@ def test_golden_flow(tnf, fusion, flow_variant):
         fast = tnf.ops.has_fast_path(D, L, U)
         if fusion in ("layer", "flow") and not fast:
             continue
+        if fusion == "flow" and not tnf._lib.lib.tnf_flow_fused_supported(D, S, L, U):
+            continue
         nf.params = T(g[k + "params"])
         _install_stats(nf, g[k + "bn_mean"], g[k + "bn_alpha"])
         nf.fusion = {"auto": L_.FUSE_AUTO, "layer": L_.FUSE_LAYER, "flow": L_.FUSE_FLOW,
@@ -205,13 +207,19 @@ def _rand_flow(tnf, D, S, L, U, seed, sigma=0.1, M=1):
 
 @pytest.mark.parametrize("D,S,L,U,N", [(64, 4, 2, 15, 16384), (32, 4, 2, 15, 16384), (64, 1, 1, 16, 1000),
                                        (32, 2, 3, 15, 4097), (64, 4, 2, 15, 31), (2, 1, 2, 15, 1024),
-                                       (6, 2, 2, 20, 513)])
+                                       (6, 2, 2, 20, 513),
+                                       # shapes of the wide per-layer MFMA kernel (D % 8 == 0, U <= 64, L <= 5)
+                                       (64, 2, 2, 20, 2049), (64, 2, 2, 64, 1000), (16, 3, 2, 15, 777),
+                                       (8, 2, 3, 20, 333), (128, 1, 2, 32, 500), (24, 2, 5, 17, 450),
+                                       (40, 2, 1, 50, 129), (64, 4, 4, 15, 64)])
 def test_oracle_log_prob(tnf, oracle, flow_variant, D, S, L, U, N):
     nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=N + D)
     z = torch.randn(1, N, D, generator=torch.Generator().manual_seed(1))
     want = oracle.flow_log_prob(z, params, D, S, L, U, stats)
-    for fusion in ([tnf._lib.FUSE_LAYER, tnf._lib.FUSE_FLOW] if tnf.ops.has_fast_path(D, L, U)
-                   else [tnf._lib.FUSE_AUTO]):
+    fusions = [tnf._lib.FUSE_AUTO]
+    if tnf.ops.has_fast_path(D, L, U):
+        fusions = [tnf._lib.FUSE_LAYER] + ([tnf._lib.FUSE_FLOW] if tnf._lib.lib.tnf_flow_fused_supported(D, S, L, U) else [])
+    for fusion in fusions:
         nf.fusion = fusion
         with torch.no_grad():
             got = nf.log_prob(z.cuda(), params.cuda())

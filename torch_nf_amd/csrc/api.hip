@@ -42,13 +42,17 @@ static int64_t round16(int64_t b) { return (b + 15) & ~(int64_t)15; }
 struct FlowWs {
     int64_t fold, ldc, images, zbuf, ldbuf, total;
 };
-static FlowWs flow_ws(int64_t M, int64_t N, int D, int S) {
+static int64_t flow_image_slot(int D, int L, int U) {
+    // narrow shapes: fp32 and split-f16 images share one slot size (the L = 3 fp32 image);
+    // wide shapes: the wide image of exactly this (D, L, U)
+    return mfma_supported(D, L, U) ? mfma_image_floats(D, 3) : wide_image_floats(D, L, U);
+}
+static FlowWs flow_ws(int64_t M, int64_t N, int D, int S, int L, int U) {
     FlowWs w;
     w.fold = 0;
     w.ldc = round16(M * 2 * S * 2 * D * (int64_t)sizeof(float));
     w.images = w.ldc + round16(M * (int64_t)sizeof(float));
-    // operand images sized for the widest supported MLP (L = 3): the size query does not know L
-    w.zbuf = w.images + round16(M * 2 * S * mfma_image_floats(D, 3) * (int64_t)sizeof(float));
+    w.zbuf = w.images + round16(M * 2 * S * flow_image_slot(D, L, U) * (int64_t)sizeof(float));
     w.ldbuf = w.zbuf + round16(M * N * D * (int64_t)sizeof(float));
     w.total = w.ldbuf + round16(M * N * (int64_t)sizeof(float));
     return w;
@@ -91,7 +95,9 @@ int64_t tnf_flow_num_params(int32_t D, int32_t S, int32_t L, int32_t U) {
     return flow_layout(D, S, L, U).total;
 }
 
-int tnf_has_fast_path(int32_t D, int32_t L, int32_t U) { return mfma_supported(D, L, U) ? 1 : 0; }
+int tnf_has_fast_path(int32_t D, int32_t L, int32_t U) {
+    return (mfma_supported(D, L, U) || wide_supported(D, L, U)) ? 1 : 0;
+}
 
 int tnf_coupling(int32_t dtype, const void* z, const void* params, void* z_out, void* log_det,
                  int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U,
@@ -125,6 +131,20 @@ int tnf_coupling(int32_t dtype, const void* z, const void* params, void* z_out, 
         a.Mz = M_z; a.Mp = M_p; a.N = N;
         a.D = D; a.L = L; a.U = U; a.upper = upper; a.inverse = inverse;
         return launch_coupling_mfma(a, st);
+    }
+    if (dtype == TNF_F32 && !g_force_generic && wide_supported(D, L, U) && N >= 16 && aligned16(z) && aligned16(z_out)) {
+        MfmaLayerArgs a;
+        memset(&a, 0, sizeof(a));
+        a.z = (const float*)z;
+        a.z_out = (float*)z_out;
+        a.params = (const float*)params;
+        a.pstride = pstride;
+        a.ld_in = ld_mode == TNF_LD_STORE ? nullptr : (const float*)log_det;
+        a.ld_out = (float*)log_det;
+        a.ld_sign = ld_mode == TNF_LD_SUB ? -1.f : 1.f;
+        a.Mz = M_z; a.Mp = M_p; a.N = N;
+        a.D = D; a.L = L; a.U = U; a.upper = upper; a.inverse = inverse;
+        return launch_coupling_wide(a, st);
     }
     return launch_coupling_generic(dtype, z, params, z_out, log_det, M_z, M_p, N, D, L, U, upper,
                                    inverse, pstride, ld_mode, st);
@@ -230,10 +250,14 @@ int tnf_flow_fused_supported(int32_t D, int32_t S, int32_t L, int32_t U) {
     return flow_fused_supported(D, S, L, U) ? 1 : 0;
 }
 
-int64_t tnf_flow_workspace_bytes(int64_t M, int64_t N, int32_t D, int32_t S, int32_t fusion) {
-    if (M < 1 || N < 0 || D < 1 || S < 1)
-        return fail(TNF_EINVAL, "tnf_flow_workspace_bytes: M=%lld N=%lld D=%d S=%d", (long long)M, (long long)N, D, S);
-    const FlowWs w = flow_ws(M, N, D, S);
+int64_t tnf_flow_workspace_bytes(int64_t M, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,
+                                 int32_t fusion) {
+    if (M < 1 || N < 0 || D < 1 || S < 1 || L < 1 || U < 1)
+        return fail(TNF_EINVAL, "tnf_flow_workspace_bytes: M=%lld N=%lld D=%d S=%d L=%d U=%d", (long long)M,
+                    (long long)N, D, S, L, U);
+    if (!mfma_supported(D, L, U) && !wide_supported(D, L, U))
+        return fail(TNF_EUNSUPPORTED, "tnf_flow_workspace_bytes: no fused kernel for D=%d L=%d U=%d", D, L, U);
+    const FlowWs w = flow_ws(M, N, D, S, L, U);
     return fusion == TNF_FUSE_FLOW ? w.zbuf : w.total;  // the whole-flow kernel needs no z / log-det scratch
 }
 
@@ -246,7 +270,7 @@ static int flow_common_checks(const char* fn, int64_t M_z, int64_t M_p, int64_t 
     if (pstride < flow_layout(D, S, L, U).total)
         return fail(TNF_EINVAL, "%s: params row has %lld elements, flow needs %lld", fn,
                     (long long)pstride, (long long)flow_layout(D, S, L, U).total);
-    if (!mfma_supported(D, L, U))
+    if (!mfma_supported(D, L, U) && !wide_supported(D, L, U))
         return fail(TNF_EUNSUPPORTED, "%s: no fused kernel for D=%d L=%d U=%d (compose bijector-level calls)", fn, D, L, U);
     if (fusion == TNF_FUSE_AUTO) *use_fused = flow_fused_supported(D, S, L, U) ? 1 : 0;
     else if (fusion == TNF_FUSE_FLOW) {
@@ -256,7 +280,7 @@ static int flow_common_checks(const char* fn, int64_t M_z, int64_t M_p, int64_t 
     } else if (fusion == TNF_FUSE_LAYER) *use_fused = 0;
     else return fail(TNF_EINVAL, "%s: fusion %d", fn, fusion);
     const int64_t M = M_z > M_p ? M_z : M_p;
-    const FlowWs w = flow_ws(M, N, D, S);
+    const FlowWs w = flow_ws(M, N, D, S, L, U);
     const int64_t need = *use_fused ? w.zbuf : w.total;
     if (!ws || ws_bytes < need)
         return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)ws_bytes, (long long)need);
@@ -280,14 +304,20 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
     if (N == 0) return TNF_OK;
     hipStream_t st = as_stream(stream);
     const int64_t M = M_z > M_p ? M_z : M_p;
-    const FlowWs w = flow_ws(M, N, D, S);
+    const FlowWs w = flow_ws(M, N, D, S, L, U);
     char* wsb = reinterpret_cast<char*>(workspace);
     float* fold = reinterpret_cast<float*>(wsb + w.fold);
     float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
     float* images = reinterpret_cast<float*>(wsb + w.images);
-    const int64_t img_floats = mfma_image_floats(D, L);
-    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 1, st);
+    const bool narrow = mfma_supported(D, L, U);
+    const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
+    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride,
+                          1, st);
     if (rc) return rc;
+    if (!narrow) {
+        rc = launch_wide_images(params, images, M_p, D, S, L, U, pstride, st);
+        if (rc) return rc;
+    }
     if (use_fused && g_flow_variant >= 10) {
         rc = launch_flow_images_f16(params, images, M_p, D, S, L, U, pstride, st);
         if (rc) return rc;
@@ -322,7 +352,7 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
         a.log_prob = last ? log_prob : nullptr;
         a.Mz = first ? M_z : M; a.Mp = M_p; a.N = N;
         a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 1;
-        rc = launch_coupling_mfma(a, st);
+        rc = narrow ? launch_coupling_mfma(a, st) : launch_coupling_wide(a, st);
         if (rc) return rc;
     }
     return TNF_OK;
@@ -345,14 +375,20 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
     if (N == 0) return TNF_OK;
     hipStream_t st = as_stream(stream);
     const int64_t M = M_z > M_p ? M_z : M_p;
-    const FlowWs w = flow_ws(M, N, D, S);
+    const FlowWs w = flow_ws(M, N, D, S, L, U);
     char* wsb = reinterpret_cast<char*>(workspace);
     float* fold = reinterpret_cast<float*>(wsb + w.fold);
     float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
     float* images = reinterpret_cast<float*>(wsb + w.images);
-    const int64_t img_floats = mfma_image_floats(D, L);
-    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 0, st);
+    const bool narrow = mfma_supported(D, L, U);
+    const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
+    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride,
+                          0, st);
     if (rc) return rc;
+    if (!narrow) {
+        rc = launch_wide_images(params, images, M_p, D, S, L, U, pstride, st);
+        if (rc) return rc;
+    }
     if (use_fused && g_flow_variant >= 10) {
         rc = launch_flow_images_f16(params, images, M_p, D, S, L, U, pstride, st);
         if (rc) return rc;
@@ -383,7 +419,7 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
         a.add_ldc = last ? 1 : 0;
         a.Mz = first ? M_z : M; a.Mp = M_p; a.N = N;
         a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 0;
-        rc = launch_coupling_mfma(a, st);
+        rc = narrow ? launch_coupling_mfma(a, st) : launch_coupling_wide(a, st);
         if (rc) return rc;
     }
     return TNF_OK;

@@ -93,6 +93,7 @@ int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_
                      int64_t pstride, int inverse, hipStream_t st) {
     hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
                        bn_alpha, fold, ldc, D, S, L, U, pstride, inverse);
+    if (!images) return check_launch("flow_prep");  // wide shapes build their own images
     const dim3 grid = grid_xm(2 * S, Mp);
     const int64_t fl = mfma_image_floats(D, L);
 #define TNF_IMG(HH, LL) \

@@ -98,6 +98,13 @@ struct MfmaLayerArgs {
 };
 int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st);
 
+// wide per-layer kernel (coupling_wide.hip): D % 8 == 0, D <= 128, U <= 64, L <= 5
+bool wide_supported(int D, int L, int U);
+int64_t wide_image_floats(int D, int L, int U);
+int launch_coupling_wide(const MfmaLayerArgs& a, hipStream_t st);
+int launch_wide_images(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,
+                       int64_t pstride, hipStream_t st);
+
 // Per-call preparation for the flow-level chains: fold BN/Affine constants (fold: (Mp, 2S, 2, D),
 // ldc: (Mp)) and build the lane-ordered MFMA operand images (Mp, 2S, mfma_image_floats(D, L)).
 int64_t mfma_image_floats(int D, int L);

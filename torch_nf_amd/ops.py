@@ -298,7 +298,7 @@ def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE
     sld = torch.empty((M, N), dtype=torch.float32, device=dev) if want_sld else None
     if N == 0:
         return tuple(t.to(home) if t is not None else None for t in (lp, z0, sld))
-    ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, fusion))
+    ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, L, U, fusion))
     ws = _workspace(ws_bytes, dev)
     check(lib.tnf_flow_log_prob_f32(
         zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
@@ -331,7 +331,7 @@ def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.F
     sld = torch.empty((M, N), dtype=torch.float32, device=dev)
     if N == 0:
         return z_out.to(home), sld.to(home)
-    ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, fusion))
+    ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, L, U, fusion))
     ws = _workspace(ws_bytes, dev)
     check(lib.tnf_flow_forward_f32(oc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
                                    z_out.data_ptr(), sld.data_ptr(), Mz, Mp, N, D, S, L, U, pstride,
