@@ -142,6 +142,14 @@ int tnf_affine_backward(int32_t dtype, const void* z, const void* params, const 
 int tnf_bn_apply_backward(int32_t dtype, const void* g_z_out, const float* alpha, void* g_z, int64_t rows,
                           int32_t D, int32_t inverse, void* stream);
 
+/* Backward of tnf_bn_batch_forward_f32: with x^ = z_out of the forward call and n = rows,
+ *   g_z = (g - mean(g) - x^ (mean(g x^) + g_log_det/n)) / alpha
+ * g_log_det: device pointer to ONE float (gradient w.r.t. the 0-dim log_det), may be NULL (= 0).
+ * workspace: tnf_bn_batch_workspace_bytes(D) bytes. */
+int tnf_bn_batch_backward_f32(const float* z_norm, const float* g_z_out, const float* g_log_det,
+                              const float* alpha, float* g_z, int64_t rows, int32_t D, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
 /* Base density of NormFlow.forward, float64 like the reference's numpy expression
  * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as
  * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)) in float64.  omega (rows, D) of `dtype` (TNF_F64 for

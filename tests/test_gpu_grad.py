@@ -126,3 +126,40 @@ def test_cde_training_step(tnf, oracle):
         torch.testing.assert_close(got.grad.cpu(), want.grad, rtol=1e-3, atol=1e-4)  # param_net GEMMs: hipBLASLt vs MKL
     opt = torch.optim.Adam(cde.parameters(), lr=1e-3)
     opt.step()
+
+
+def test_bn_batch_grad(tnf, oracle):
+    """Batch-statistics BatchNorm: gradients through the normalisation, the batch moments and the
+    log-det, against torch autograd over the reference's expression (bijectors.py:401-417)."""
+    rng = np.random.RandomState(12)
+    for D, M, N, loc in [(6, 3, 40, 2.0), (64, 1, 500, -1.0)]:
+        z0 = torch.tensor(rng.normal(loc, 1.5, (M, N, D))).float()
+        w = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+        zr = z0.clone().requires_grad_()
+        zn_ref, ld_ref, _, _ = oracle.bn_forward_batch(zr)
+        ((zn_ref * w).sum() + 3.0 * ld_ref).backward()
+        bn = tnf.BatchNorm(D)
+        z = z0.cuda().requires_grad_()
+        zn, ld = bn(z)
+        ((zn * w.cuda()).sum() + 3.0 * ld).backward()
+        torch.testing.assert_close(z.grad.cpu(), zr.grad, rtol=2e-3, atol=2e-4)
+
+
+def test_forward_path_training_grad(tnf, oracle):
+    """EFN-style objective on the sampling path (freeze_bn=False): d mean(log_q) / d params flows
+    through coupling layers, Affine and batch-statistics BatchNorm (two_network_arch notebook)."""
+    D, S, L, U, N = 8, 2, 2, 15, 400
+    rng = np.random.RandomState(4)
+    nf = tnf.NormFlow(D, False, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.1, (1, nf.D_params))).float()
+    omega = rng.normal(0, 1, (1, N, D))
+    nf.params = p0.cuda().requires_grad_()
+    z, lq = nf._forward_from(omega, nf.params, freeze_bn=False)
+    loss = lq.mean() + (z ** 2).mean()
+    loss.backward()
+    p_ref = p0.clone().requires_grad_()
+    z_r, lq_r, _ = oracle.flow_forward(omega, p_ref, D, S, L, U, None)
+    loss_r = lq_r.mean() + (z_r ** 2).mean()
+    loss_r.backward()
+    torch.testing.assert_close(loss.detach().cpu(), loss_r.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(nf.params.grad.cpu(), p_ref.grad, rtol=5e-3, atol=2e-5)

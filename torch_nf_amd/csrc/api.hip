@@ -238,6 +238,18 @@ int tnf_bn_apply_backward(int32_t dtype, const void* g_z_out, const float* alpha
     return launch_bn_apply_backward(dtype, g_z_out, alpha, g_z, rows, D, inverse, as_stream(stream));
 }
 
+int tnf_bn_batch_backward_f32(const float* z_norm, const float* g_z_out, const float* g_log_det,
+                              const float* alpha, float* g_z, int64_t rows, int32_t D, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    if (rows < 2 || D < 1) return fail(TNF_EINVAL, "tnf_bn_batch_backward_f32: rows=%lld D=%d", (long long)rows, D);
+    if (!z_norm || !g_z_out || !alpha || !g_z || !workspace)
+        return fail(TNF_EINVAL, "tnf_bn_batch_backward_f32: NULL pointer");
+    if (workspace_bytes < tnf_bn_batch_workspace_bytes(D))
+        return fail(TNF_EWORKSPACE, "tnf_bn_batch_backward_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)tnf_bn_batch_workspace_bytes(D));
+    return launch_bn_batch_backward(z_norm, g_z_out, g_log_det, alpha, g_z, rows, D, workspace, as_stream(stream));
+}
+
 int tnf_base_log_density_f64(int32_t dtype, const void* omega, double* out, int64_t rows, int32_t D,
                              void* stream) {
     if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_base_log_density_f64: dtype %d", dtype);

@@ -363,4 +363,82 @@ int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, 
     return check_launch("bn_apply_backward");
 }
 
+// ---------------------------------------------------------------------------
+// BatchNorm with batch statistics (bijectors.py:401-417), backward.  With x^ = (z - mu)/alpha,
+// alpha = sqrt(var_b + eps), log_det = -sum_d log alpha_d and n rows:
+//   dz = (1/alpha) [ g - mean(g) - x^ (mean(g x^) + g_ld / n) ]
+// (the usual batch-norm backward plus d log_det/dz = -x^/(n alpha)).  Two passes: per-feature
+// sums of g and g*x^ in float64 (block partials -> double atomics), then elementwise.
+// workspace: 2*D doubles.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bn_batch_bwd_sums_kernel(const float* __restrict__ zn, const float* __restrict__ g, double* __restrict__ sums,
+                         int64_t rows, int D, int64_t rows_per_block) {
+    __shared__ double red1[256];
+    __shared__ double red2[256];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int dc = 0; dc < D; dc += 256) {
+        const int Dc = (D - dc) < 256 ? (D - dc) : 256;
+        const int rpi = 256 / Dc;
+        const int r = tid / Dc, d = tid - r * Dc;
+        double s1 = 0.0, s2 = 0.0;
+        if (r < rpi) {
+            for (int64_t row = r0 + r; row < r1; row += rpi) {
+                const double gv = (double)g[row * D + dc + d];
+                s1 += gv;
+                s2 += gv * (double)zn[row * D + dc + d];
+            }
+        }
+        red1[tid] = s1;
+        red2[tid] = s2;
+        __syncthreads();
+        if (tid < Dc) {
+            double a = 0.0, b = 0.0;
+            for (int rr = 0; rr < rpi; ++rr) {
+                a += red1[rr * Dc + tid];
+                b += red2[rr * Dc + tid];
+            }
+            atomicAdd(&sums[dc + tid], a);
+            atomicAdd(&sums[D + dc + tid], b);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_batch_bwd_apply_kernel(const float* __restrict__ zn, const float* __restrict__ g,
+                          const float* __restrict__ g_ld, const float* __restrict__ alpha,
+                          const double* __restrict__ sums, float* __restrict__ g_z, int64_t rows, int D,
+                          int64_t total) {
+    const double inv_n = 1.0 / (double)rows;
+    const double gl = g_ld ? (double)*g_ld : 0.0;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int d = (int)(idx % D);
+        const float mg = (float)(sums[d] * inv_n);
+        const float mgx = (float)((sums[D + d] + gl) * inv_n);
+        g_z[idx] = (g[idx] - mg - zn[idx] * mgx) / alpha[d];
+    }
+}
+
+int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
+                             int64_t rows, int D, void* ws, hipStream_t st) {
+    double* sums = reinterpret_cast<double*>(ws);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)D, st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "bn_batch_backward: memset failed");
+    int64_t blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const int64_t rpb = (rows + blocks - 1) / blocks;
+    hipLaunchKernelGGL(bn_batch_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, zn, g, sums, rows, D, rpb);
+    const int64_t total = rows * D;
+    int64_t nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(bn_batch_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, zn, g, g_ld, alpha, sums, g_z,
+                       rows, D, total);
+    return check_launch("bn_batch_backward");
+}
+
 }  // namespace tnf

@@ -46,7 +46,7 @@ __device__ __forceinline__ void apply_fold(const float* fc, int q, f4 (&lo)[NT][
     }
 }
 
-template <int H, int L, bool INV, int NT, int NWAVES, bool SKEW>
+template <int H, int L, bool INV, int NT, int NWAVES>
 __global__ void __launch_bounds__(NWAVES * 64)
 flow_fused_kernel(FlowFusedArgs a) {
     constexpr int D = 2 * H;
@@ -110,14 +110,6 @@ flow_fused_kernel(FlowFusedArgs a) {
         }
     }
 
-    auto layer = [&]<bool I>(const float* im, int ln, const f4 (&xx)[NT][HT], f4 (&yy)[NT][HT],
-                             float (&ss)[NT]) __attribute__((always_inline)) {
-        if constexpr (SKEW && NT == 2)
-            coupling_tile_skewed<H, L, I>(LdsOperands<H, L>(im, ln), xx, yy, ss);
-        else
-            coupling_tile<H, L, I, NT>(LdsOperands<H, L>(im, ln), xx, yy, ss);
-    };
-
     for (;;) {
         int nxt_off = 0;
         if (lane == 0) nxt_off = atomicAdd(qhead, 1);
@@ -153,17 +145,17 @@ flow_fused_kernel(FlowFusedArgs a) {
             for (int st = a.S - 1; st >= 0; --st) {
                 const int c1 = 2 * st + 1, c0 = 2 * st;
                 apply_fold<H, NT>(fold + c1 * 2 * D, q, lo, hi);  // Affine^-1, BN^-1
-                layer.template operator()<true>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
+                coupling_tile<H, L, true, NT>(LdsOperands<H, L>(img + c1 * Img::FLOATS, lane), hi, lo, ssum);
                 apply_fold<H, NT>(fold + c0 * 2 * D, q, lo, hi);  // BN^-1
-                layer.template operator()<true>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
+                coupling_tile<H, L, true, NT>(LdsOperands<H, L>(img + c0 * Img::FLOATS, lane), lo, hi, ssum);
             }
         } else {
             // density_estimator.py:375-387
             for (int st = 0; st < a.S; ++st) {
                 const int c0 = 2 * st, c1 = 2 * st + 1;
-                layer.template operator()<false>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
+                coupling_tile<H, L, false, NT>(LdsOperands<H, L>(img + c0 * Img::FLOATS, lane), lo, hi, ssum);
                 apply_fold<H, NT>(fold + c0 * 2 * D, q, lo, hi);  // BN
-                layer.template operator()<false>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
+                coupling_tile<H, L, false, NT>(LdsOperands<H, L>(img + c1 * Img::FLOATS, lane), hi, lo, ssum);
                 apply_fold<H, NT>(fold + c1 * 2 * D, q, lo, hi);  // BN, Affine
             }
         }
@@ -233,10 +225,10 @@ bool flow_fused_supported(int D, int S, int L, int U) {
     return flow_lds_bytes_rt(D, S, L) <= 160 * 1024;
 }
 
-template <int H, int L, bool INV, int NT, int NW, bool SKEW = false>
+template <int H, int L, bool INV, int NT, int NW>
 static int launch_t(const FlowFusedArgs& a, int64_t M, hipStream_t st) {
     const size_t smem = flow_lds_bytes<H, L>(a.S);
-    auto kern = flow_fused_kernel<H, L, INV, NT, NW, SKEW>;
+    auto kern = flow_fused_kernel<H, L, INV, NT, NW>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_fused: cannot reserve %zu B of LDS", smem);
     const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
@@ -255,7 +247,6 @@ static int launch_v(const FlowFusedArgs& a, int64_t M, hipStream_t st) {
             case 2: return launch_t<H, L, INV, 1, 12>(a, M, st);
             case 3: return launch_t<H, L, INV, 1, 16>(a, M, st);
             case 4: return launch_t<H, L, INV, 2, 12>(a, M, st);
-            case 5: return launch_t<H, L, INV, 2, 8, true>(a, M, st);
             default: break;
         }
     }

@@ -36,9 +36,6 @@
 #ifndef TNF_ABLATE
 #define TNF_ABLATE 0
 #endif
-#ifndef TNF_SKEW_SCHED
-#define TNF_SKEW_SCHED 0
-#endif
 
 namespace tnf {
 
@@ -381,126 +378,6 @@ __device__ __forceinline__ void coupling_tile(const OP& op, const f4 (&x)[NT][(H
                     y[t][mo][j] = __builtin_fmaf(y[t][mo][j], __builtin_amdgcn_exp2f(s2), tt[t][j]);
             }
     }
-}
-
-// ---------------------------------------------------------------------------
-// Two-tile software pipeline of one coupling layer (whole-flow kernel, MFMA-bound).
-// A tile's layer is the stage chain  S0 V0 [S1 V1 ...] S2 V2  where the S stages are
-// MFMA chains and the V stages the VALU work that depends on them (sigmoids, the
-// scale-shift).  Running both tiles in lock-step leaves the matrix pipe idle during
-// every V stage; here tile B lags tile A by one stage, so each bracket pairs one tile's
-// MFMAs with the other tile's VALU work, and sched_group_barrier pins the interleave.
-// ---------------------------------------------------------------------------
-template <int H>
-struct TileRegs {
-    static constexpr int HT = (H + 15) / 16;
-    f4 at, as;
-    f4 tt[HT], sv[HT];
-};
-
-template <int K, int H, int L, bool INV, class OP>
-__device__ __forceinline__ void run_stage(const OP& op, TileRegs<H>& r, const f4 (&x)[(H + 15) / 16],
-                                          f4 (&y)[(H + 15) / 16], float& ssum2) {
-    constexpr int HT = (H + 15) / 16;
-    if constexpr (K == 0) {  // S0: H -> U
-        r.at = op.b0(0);
-        r.as = op.b0(1);
-#pragma unroll
-        for (int m = 0; m < HT; ++m) {
-            const f4 wt = op.w0(0, m), ws = op.w0(1, m);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r.at = mfma4(wt[j], x[m][j], r.at);
-                r.as = mfma4(ws[j], x[m][j], r.as);
-            }
-        }
-    } else if constexpr (K < 2 * L && (K & 1)) {  // V: r = 1/(2^acc + 1)
-        r.at = sig2_4(r.at);
-        r.as = sig2_4(r.as);
-    } else if constexpr (K < 2 * L) {  // hidden layer l = K/2 - 1: U -> U
-        constexpr int l = K / 2 - 1;
-        const f4 wt = op.wh(l, 0), ws = op.wh(l, 1);
-        f4 nt = op.bh(l, 0), ns = op.bh(l, 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            nt = mfma4(wt[j], r.at[j], nt);
-            ns = mfma4(ws[j], r.as[j], ns);
-        }
-        r.at = nt;
-        r.as = ns;
-    } else if constexpr (K == 2 * L) {  // S2: U -> H
-#pragma unroll
-        for (int mo = 0; mo < HT; ++mo) {
-            r.tt[mo] = op.b2(0, mo);
-            r.sv[mo] = op.b2(1, mo);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mo = 0; mo < HT; ++mo) {
-                r.tt[mo] = mfma4(op.w2(0, mo)[j], r.at[j], r.tt[mo]);
-                r.sv[mo] = mfma4(op.w2(1, mo)[j], r.as[j], r.sv[mo]);
-            }
-    } else {  // V2: scale-shift + log-det share
-#pragma unroll
-        for (int mo = 0; mo < HT; ++mo)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s2 = r.sv[mo][j];
-                ssum2 += s2;
-                if (INV)
-                    y[mo][j] = (y[mo][j] - r.tt[mo][j]) * __builtin_amdgcn_exp2f(-s2);
-                else
-                    y[mo][j] = __builtin_fmaf(y[mo][j], __builtin_amdgcn_exp2f(s2), r.tt[mo][j]);
-            }
-    }
-}
-
-template <int NM, int NV>
-__device__ __forceinline__ void interleave_mfma_valu() {
-    // NM MFMAs, each followed by NV VALU instructions, in program order
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  // VALU
-    }
-}
-
-template <int I, int H, int L, bool INV, class OP>
-__device__ __forceinline__ void skew_bracket(const OP& op, TileRegs<H>& ra, TileRegs<H>& rb,
-                                             const f4 (&xa)[(H + 15) / 16], f4 (&ya)[(H + 15) / 16],
-                                             const f4 (&xb)[(H + 15) / 16], f4 (&yb)[(H + 15) / 16],
-                                             float& sa, float& sb) {
-    constexpr int HT = (H + 15) / 16;
-    constexpr int NS = 2 * L + 2;
-    if constexpr (I <= NS) {
-        if constexpr (I < NS) run_stage<I, H, L, INV>(op, ra, xa, ya, sa);
-        if constexpr (I >= 1) run_stage<I - 1, H, L, INV>(op, rb, xb, yb, sb);
-        // which stream holds the MFMAs in this bracket, and how many
-        constexpr int KM = (I & 1) ? I - 1 : I;  // the even (MFMA) stage index present
-        constexpr bool has_m = (I & 1) ? true : (I < NS);
-        constexpr int NM = !has_m ? 0 : (KM == 0 ? 8 * HT : (KM == 2 * L ? 8 * HT : 8));
-        constexpr int KV = (I & 1) ? I : I - 1;  // the odd (VALU) stage index present
-        constexpr bool has_v = (I & 1) ? (I < NS) : (I >= 1);
-        constexpr int NVt = !has_v ? 0 : (KV == 2 * L + 1 ? 4 * 4 * HT : 24);
-#if TNF_SKEW_SCHED == 2
-        if constexpr (NM > 0 && NVt > 0) interleave_mfma_valu<NM, (NVt + NM - 1) / NM>();
-        __builtin_amdgcn_sched_barrier(0);
-#elif TNF_SKEW_SCHED == 1
-        __builtin_amdgcn_sched_barrier(0);
-#elif TNF_SKEW_SCHED == 3
-        if constexpr (NM > 0 && NVt > 0) interleave_mfma_valu<NM, (NVt + NM - 1) / NM>();
-#endif
-        skew_bracket<I + 1, H, L, INV>(op, ra, rb, xa, ya, xb, yb, sa, sb);
-    }
-}
-
-// One coupling layer on two tiles, tile B one stage behind tile A.
-template <int H, int L, bool INV, class OP>
-__device__ __forceinline__ void coupling_tile_skewed(const OP& op, const f4 (&x)[2][(H + 15) / 16],
-                                                     f4 (&y)[2][(H + 15) / 16], float (&ssum2)[2]) {
-    TileRegs<H> ra, rb;
-    skew_bracket<0, H, L, INV>(op, ra, rb, x[0], y[0], x[1], y[1], ssum2[0], ssum2[1]);
 }
 
 }  // namespace tnf

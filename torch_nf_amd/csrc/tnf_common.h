@@ -145,6 +145,8 @@ int launch_affine_backward(int dtype, const void* z, const void* params, const v
 int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, void* g_z, int64_t rows,
                              int D, int inverse, hipStream_t st);
 
+int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
+                             int64_t rows, int D, void* ws, hipStream_t st);
 int launch_base_log_density(int dtype, const void* omega, double* out, int64_t rows, int D, hipStream_t st);
 
 }  // namespace tnf

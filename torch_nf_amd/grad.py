@@ -81,3 +81,21 @@ def bn_apply_backward(g_z, alpha, inverse):
     check(lib.tnf_bn_apply_backward(code, gc.data_ptr(), ac.data_ptr(), out.data_ptr(), gc.numel() // D, D,
                                     int(inverse), _lib.stream_ptr()))
     return out if home == dev else out.to(home)
+
+
+def bn_batch_backward(z_norm, alpha, g_zn, g_ld):
+    dev = _lib.require_device()
+    home = z_norm.device
+    zc = _dev(z_norm.detach(), dev).contiguous()
+    D = zc.shape[-1]
+    rows = zc.numel() // D
+    gc = torch.zeros_like(zc) if g_zn is None else _dev(g_zn, dev).contiguous().float()
+    gl = None if g_ld is None else _dev(g_ld, dev).reshape(1).float().contiguous()
+    ac = _dev(alpha.detach().float(), dev).contiguous()
+    out = torch.empty_like(zc)
+    ws_bytes = lib.tnf_bn_batch_workspace_bytes(D)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    check(lib.tnf_bn_batch_backward_f32(zc.data_ptr(), gc.data_ptr(), None if gl is None else gl.data_ptr(),
+                                        ac.data_ptr(), out.data_ptr(), rows, D, ws.data_ptr(), ws_bytes,
+                                        _lib.stream_ptr()))
+    return out if home == dev else out.to(home)

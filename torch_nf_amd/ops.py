@@ -207,8 +207,33 @@ def bn_apply(z, mean, alpha, inverse):
     return bn_apply_raw(z, mean, alpha, inverse)
 
 
+class _BnBatchFn(torch.autograd.Function):
+    """Batch-statistics BatchNorm with gradients to z (through the normalisation, the batch
+    moments and the log-det).  mean / alpha are returned as constants."""
+
+    @staticmethod
+    def forward(ctx, z, eps):
+        z_norm, log_det, mean, alpha = _bn_batch_forward_raw(z, eps)
+        ctx.save_for_backward(z_norm, alpha)
+        ctx.mark_non_differentiable(mean, alpha)
+        return z_norm, log_det, mean, alpha
+
+    @staticmethod
+    def backward(ctx, g_zn, g_ld, _g_mean, _g_alpha):
+        from . import grad
+
+        z_norm, alpha = ctx.saved_tensors
+        return grad.bn_batch_backward(z_norm, alpha, g_zn, g_ld), None
+
+
 def bn_batch_forward(z, eps):
     """Batch-statistics BatchNorm forward (float32).  Returns (z_norm, log_det, mean, alpha)."""
+    if torch.is_grad_enabled() and z.requires_grad:
+        return _BnBatchFn.apply(z, eps)
+    return _bn_batch_forward_raw(z, eps)
+
+
+def _bn_batch_forward_raw(z, eps):
     _check3(z)
     if z.dtype != torch.float32:
         raise TypeError("BatchNorm batch statistics are implemented for float32 (got %s)" % z.dtype)
