@@ -106,8 +106,8 @@ int tnf_affine(int32_t dtype, const void* z, const void* params, void* z_out, vo
 
 /* BatchNorm with cached statistics: inverse != 0 -> z*alpha + mean
  * (bijectors.py:420-426); inverse == 0 -> (z - mean)/alpha, the use_last=True
- * branch (bijectors.py:397-399).  log_det (1 element of `dtype`... always float32)
- * receives -sum(log(alpha)).  rows = M*N. */
+ * branch (bijectors.py:397-399).  log_det (one float32, like the statistics) receives
+ * -sum(log(alpha)).  rows = M*N. */
 int tnf_bn_apply(int32_t dtype, const void* z, const float* mean, const float* alpha, void* z_out,
                  float* log_det, int64_t rows, int32_t D, int32_t inverse, void* stream);
 
