@@ -177,6 +177,26 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
                           int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                           int32_t fusion, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Training pair for loss = f(NormFlow.log_prob(z)) (the reference differentiates
+ * density_estimator.py:390-416 with torch autograd).  The forward runs one fused kernel per
+ * coupling layer and keeps each kernel's INPUT in `states` (2*S - 1, M, N, D) -- states[c] is the
+ * input of layer kernel c; the last-applied layer's input is z itself.  The backward walks the
+ * layers the other way with one MFMA backward kernel each (recompute, folded BatchNorm/Affine,
+ * base density on the first), accumulating into g_params (M_p rows of g_params_row_stride floats,
+ * zero it first; float atomics) and writing g_z (M,N,D).  M_p is 1 or M; z has M rows.
+ * Available for the shapes of tnf_flow_fused_supported(); BatchNorm statistics are constants. */
+int64_t tnf_flow_train_workspace_bytes(int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t num_stages,
+                                       int32_t num_layers, int32_t num_units);
+int tnf_flow_log_prob_fwd_f32(const float* z, const float* params, const float* bn_mean, const float* bn_alpha,
+                              float* log_prob, float* states, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                              int32_t num_stages, int32_t num_layers, int32_t num_units,
+                              int64_t params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
+int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* params, const float* bn_mean,
+                              const float* bn_alpha, const float* g_log_prob, float* g_z, float* g_params,
+                              int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t num_stages,
+                              int32_t num_layers, int32_t num_units, int64_t params_row_stride,
+                              int64_t g_params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The deterministic part of NormFlow.forward with freeze_bn=True
  * (density_estimator.py:374-388): pushes base samples `omega` (M,N,D) through
  * the stack.  Outputs: z_out (M,N,D); sum_log_det (M,N) = sum of the forward

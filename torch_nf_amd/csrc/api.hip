@@ -370,6 +370,150 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
     return TNF_OK;
 }
 
+// ---- training pair: log_prob with saved per-layer inputs, and its backward ----
+struct TrainWs {
+    int64_t fold, ldc, images, gfold, ldbuf, gbuf, total;
+};
+static TrainWs train_ws(int64_t M, int64_t Mp, int64_t N, int D, int S, int L) {
+    TrainWs w;
+    w.fold = 0;
+    w.ldc = round16(Mp * 2 * S * 2 * D * (int64_t)sizeof(float));
+    w.images = w.ldc + round16(Mp * (int64_t)sizeof(float));
+    w.gfold = w.images + round16(Mp * 2 * S * mfma_image_floats(D, L) * (int64_t)sizeof(float));
+    w.ldbuf = w.gfold + round16(Mp * 2 * S * 2 * D * (int64_t)sizeof(float));
+    w.gbuf = w.ldbuf + round16(M * N * (int64_t)sizeof(float));
+    w.total = w.gbuf + 2 * round16(M * N * D * (int64_t)sizeof(float));
+    return w;
+}
+
+int64_t tnf_flow_train_workspace_bytes(int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U) {
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0 || S < 1)
+        return fail(TNF_EINVAL, "tnf_flow_train_workspace_bytes: M=%lld M_p=%lld N=%lld S=%d", (long long)M,
+                    (long long)M_p, (long long)N, S);
+    if (!mfma_supported(D, L, U))
+        return fail(TNF_EUNSUPPORTED, "tnf_flow_train_workspace_bytes: no training kernels for D=%d L=%d U=%d", D, L, U);
+    return train_ws(M, M_p, N, D, S, L).total;
+}
+
+static int train_checks(const char* fn, int64_t M, int64_t M_p, int64_t N, int D, int S, int L, int U,
+                        int64_t pstride, const void* ws, int64_t ws_bytes) {
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0 || S < 1)
+        return fail(TNF_EINVAL, "%s: M=%lld M_p=%lld N=%lld S=%d", fn, (long long)M, (long long)M_p, (long long)N, S);
+    if (!mfma_supported(D, L, U))
+        return fail(TNF_EUNSUPPORTED, "%s: no training kernels for D=%d L=%d U=%d", fn, D, L, U);
+    if (pstride < flow_layout(D, S, L, U).total)
+        return fail(TNF_EINVAL, "%s: params row has %lld elements, flow needs %lld", fn, (long long)pstride,
+                    (long long)flow_layout(D, S, L, U).total);
+    if (!ws || ws_bytes < train_ws(M, M_p, N, D, S, L).total)
+        return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)ws_bytes,
+                    (long long)train_ws(M, M_p, N, D, S, L).total);
+    return TNF_OK;
+}
+
+int tnf_flow_log_prob_fwd_f32(const float* z, const float* params, const float* bn_mean, const float* bn_alpha,
+                              float* log_prob, float* states, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                              int32_t S, int32_t L, int32_t U, int64_t pstride, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    int rc = train_checks("tnf_flow_log_prob_fwd_f32", M, M_p, N, D, S, L, U, pstride, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!z || !params || !bn_mean || !bn_alpha || !log_prob || !states)
+        return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_f32: NULL pointer");
+    if (!aligned16(z) || !aligned16(states)) return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_f32: z / states must be 16-byte aligned");
+    if (N == 0) return TNF_OK;
+    hipStream_t st = as_stream(stream);
+    const TrainWs w = train_ws(M, M_p, N, D, S, L);
+    char* wsb = reinterpret_cast<char*>(workspace);
+    float* fold = reinterpret_cast<float*>(wsb + w.fold);
+    float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
+    float* images = reinterpret_cast<float*>(wsb + w.images);
+    float* ldbuf = reinterpret_cast<float*>(wsb + w.ldbuf);
+    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 1, st);
+    if (rc) return rc;
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const int64_t img_floats = mfma_image_floats(D, L);
+    const int nl = 2 * S;
+    const int64_t plane = M * N * D;
+    for (int c = nl - 1; c >= 0; --c) {
+        MfmaLayerArgs a;
+        memset(&a, 0, sizeof(a));
+        const bool first = (c == nl - 1), last = (c == 0);
+        a.z = first ? z : states + (int64_t)c * plane;       // states[c] = input of layer kernel c
+        a.z_out = last ? nullptr : states + (int64_t)(c - 1) * plane;
+        a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+        a.pstride = pstride;
+        a.image = images + (int64_t)c * img_floats;
+        a.image_stride = (int64_t)nl * img_floats;
+        a.pre = fold + (int64_t)c * 2 * D;
+        a.fold_stride = (int64_t)nl * 2 * D;
+        a.ld_in = first ? nullptr : ldbuf;
+        a.ld_out = last ? nullptr : ldbuf;
+        a.ld_sign = 1.f;
+        a.ldc = ldc;
+        a.add_ldc = last ? 1 : 0;
+        a.log_prob = last ? log_prob : nullptr;
+        a.Mz = M; a.Mp = M_p; a.N = N;
+        a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 1;
+        rc = launch_coupling_mfma(a, st);
+        if (rc) return rc;
+    }
+    return TNF_OK;
+}
+
+int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* params, const float* bn_mean,
+                              const float* bn_alpha, const float* g_log_prob, float* g_z, float* g_params,
+                              int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,
+                              int64_t pstride, int64_t gpstride, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+    int rc = train_checks("tnf_flow_log_prob_bwd_f32", M, M_p, N, D, S, L, U, pstride, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!z || !states || !params || !bn_mean || !bn_alpha || !g_log_prob || !g_z || !g_params)
+        return fail(TNF_EINVAL, "tnf_flow_log_prob_bwd_f32: NULL pointer");
+    if (gpstride < flow_layout(D, S, L, U).total) return fail(TNF_EINVAL, "tnf_flow_log_prob_bwd_f32: g_params row too short");
+    if (N == 0) return TNF_OK;
+    hipStream_t st = as_stream(stream);
+    const TrainWs w = train_ws(M, M_p, N, D, S, L);
+    char* wsb = reinterpret_cast<char*>(workspace);
+    float* fold = reinterpret_cast<float*>(wsb + w.fold);
+    float* ldc = reinterpret_cast<float*>(wsb + w.ldc);
+    float* images = reinterpret_cast<float*>(wsb + w.images);
+    float* gfold = reinterpret_cast<float*>(wsb + w.gfold);
+    float* gbuf[2] = {reinterpret_cast<float*>(wsb + w.gbuf),
+                      reinterpret_cast<float*>(wsb + w.gbuf + round16(M * N * D * (int64_t)sizeof(float)))};
+    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 1, st);
+    if (rc) return rc;
+    if (hipMemsetAsync(gfold, 0, (size_t)(M_p * 2 * S * 2 * D) * sizeof(float), st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "tnf_flow_log_prob_bwd_f32: memset failed");
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const int64_t img_floats = mfma_image_floats(D, L);
+    const int nl = 2 * S;
+    const int64_t plane = M * N * D;
+    for (int c = 0; c < nl; ++c) {
+        BwdArgs a;
+        memset(&a, 0, sizeof(a));
+        const int64_t poff = (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+        a.z = (c == nl - 1) ? z : states + (int64_t)c * plane;
+        a.params = params + poff;
+        a.g_zout = (c == 0) ? nullptr : gbuf[(c - 1) & 1];
+        a.g_ld = g_log_prob;
+        a.ld_scale = -1.f;  // log_prob = base - sum of the layers' log-dets
+        a.g_z = (c == nl - 1) ? g_z : gbuf[c & 1];
+        a.g_params = g_params + poff;
+        a.M = M; a.Mp = M_p; a.N = N;
+        a.pstride = pstride; a.gpstride = gpstride;
+        a.U = U; a.upper = (c & 1) ? 0 : 1;
+        a.image = images + (int64_t)c * img_floats;
+        a.image_stride = (int64_t)nl * img_floats;
+        a.fold = fold + (int64_t)c * 2 * D;
+        a.g_fold = gfold + (int64_t)c * 2 * D;
+        a.fold_stride = (int64_t)nl * 2 * D;
+        a.g_lp = (c == 0) ? g_log_prob : nullptr;
+        rc = launch_coupling_backward_mfma_args(a, D, L, 1, st);
+        if (rc) return rc;
+    }
+    return launch_flow_fold_backward(params, bn_alpha, gfold, g_log_prob, g_params, M, M_p, N, D, S, L, U, pstride,
+                                     gpstride, st);
+}
+
 int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
                          const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z,
                          int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,

@@ -115,16 +115,6 @@ __device__ __forceinline__ f4 outer16(f4 a_t, f4 b_t, f4 acc) {
     return acc;
 }
 
-struct BwdArgs {
-    const float* z;
-    const float* params;
-    const float* g_zout;
-    const float* g_ld;
-    float* g_z;
-    float* g_params;
-    int64_t M, Mp, N, pstride, gpstride;
-    int U, upper;
-};
 
 template <int H, int L, bool INV>
 __global__ void __launch_bounds__(256)
@@ -135,9 +125,10 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
     typedef LdsLayerImage<H, L> FImg;
     typedef BwdImage<H, L> BImg;
     constexpr int SCR = 17 * 16;  // one padded 16x16 tile
-    __shared__ __attribute__((aligned(16))) float lds[FImg::FLOATS + BImg::FLOATS + 4 * 2 * SCR];
+    __shared__ __attribute__((aligned(16))) float lds[FImg::FLOATS + BImg::FLOATS + 4 * 2 * SCR + 2 * D];
     float* fimg = lds;
     float* bimg = lds + FImg::FLOATS;
+    float* cf = lds + FImg::FLOATS + BImg::FLOATS + 4 * 2 * SCR;  // fold constants A | B
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -149,13 +140,19 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
     float* scrA = lds + FImg::FLOATS + BImg::FLOATS + wave * 2 * SCR;
     float* scrB = scrA + SCR;
 
-    if (wave == 0) {
+    const bool has_fold = a.fold != nullptr;
+    const bool finalize = a.g_lp != nullptr;
+    if (a.image) {
+        const f4* isrc = reinterpret_cast<const f4*>(a.image + mp * a.image_stride);
+        f4* idst = reinterpret_cast<f4*>(fimg);
+        for (int i = threadIdx.x; i < FImg::FLOATS / 4; i += 256) idst[i] = isrc[i];
+    } else if (wave == 0) {
         LayerW<H, L> w;
         load_layer_w<H, L>(w, prow, a.U, lane);
         store_layer_image<H, L>(fimg, w, lane);
-    } else if (wave == 1) {
-        build_bwd_image<H, L>(bimg, prow, a.U, lane);
     }
+    if (wave == 1) build_bwd_image<H, L>(bimg, prow, a.U, lane);
+    for (int i = threadIdx.x; i < 2 * D; i += 256) cf[i] = has_fold ? a.fold[mp * a.fold_stride + i] : (i < D ? 1.f : 0.f);
     __syncthreads();
     const LdsOperands<H, L> fop(fimg, lane);
     const float* bl = bimg + lane * 4;
@@ -163,8 +160,16 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
 
     const int c_off = a.upper ? 0 : H, t_off = a.upper ? H : 0;
     const float* zb = a.z + m * a.N * D;
-    const float* gzo = a.g_zout + m * a.N * D;
+    const float* gzo = a.g_zout ? a.g_zout + m * a.N * D : nullptr;
     const float* gld = a.g_ld + m * a.N;
+    const float* glpb = finalize ? a.g_lp + m * a.N : nullptr;
+    // fold constants of this lane's features (conditioner / transformed halves)
+    // (the constants are re-read from LDS where needed: keeping them in registers costs a wave per SIMD)
+    const float* cfx = cf + c_off + 4 * q;
+    const float* cfy = cf + t_off + 4 * q;
+    f4 dAx[HT], dBx[HT], dAy[HT], dBy[HT];
+#pragma unroll
+    for (int mm = 0; mm < HT; ++mm) dAx[mm] = dBx[mm] = dAy[mm] = dBy[mm] = f4{0.f, 0.f, 0.f, 0.f};
     float* gzb = a.g_z + m * a.N * D;
 
     // gradient accumulators (persist over all tiles of this wave)
@@ -185,18 +190,34 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
         const int64_t row = tile * 16 + s;
         const bool row_ok = row < a.N;
         const int64_t rowc = row_ok ? row : a.N - 1;
-        f4 x[HT], y[HT], gx[HT], gy[HT];
+        f4 x[HT], y[HT], xs[HT], ys[HT], gx[HT], gy[HT];
+        const float glp = (finalize && row_ok) ? glpb[rowc] : 0.f;
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
             const float* zr = zb + rowc * D + 4 * q + 16 * mm;
-            const float* gr = gzo + rowc * D + 4 * q + 16 * mm;
-            x[mm] = *reinterpret_cast<const f4*>(zr + c_off);
-            y[mm] = *reinterpret_cast<const f4*>(zr + t_off);
-            gx[mm] = *reinterpret_cast<const f4*>(gr + c_off);
-            gy[mm] = *reinterpret_cast<const f4*>(gr + t_off);
+            xs[mm] = *reinterpret_cast<const f4*>(zr + c_off);
+            ys[mm] = *reinterpret_cast<const f4*>(zr + t_off);
+            {
+                const f4 ax = *reinterpret_cast<const f4*>(cfx + 16 * mm), bx = *reinterpret_cast<const f4*>(cfx + D + 16 * mm);
+                const f4 ay = *reinterpret_cast<const f4*>(cfy + 16 * mm), by = *reinterpret_cast<const f4*>(cfy + D + 16 * mm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // saved input -> layer input (folded BN / Affine)
+                    x[mm][j] = __builtin_fmaf(xs[mm][j], ax[j], bx[j]);
+                    y[mm][j] = __builtin_fmaf(ys[mm][j], ay[j], by[j]);
+                }
+            }
+            if (gzo) {
+                const float* gr = gzo + rowc * D + 4 * q + 16 * mm;
+                gx[mm] = *reinterpret_cast<const f4*>(gr + c_off);
+                gy[mm] = *reinterpret_cast<const f4*>(gr + t_off);
+            } else {  // finalize: d(-|out|^2/2)/d out * g_lp; the conditioner half of out is x itself
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gx[mm][j] = -glp * x[mm][j];
+                gy[mm] = zero;  // needs the transformed output: filled in below
+            }
             if (!row_ok) { gx[mm] = zero; gy[mm] = zero; }  // padded rows contribute nothing
         }
-        const float gl = row_ok ? gld[rowc] : 0.f;
+        const float gl = row_ok ? a.ld_scale * gld[rowc] : 0.f;
 
         // ---- 1. recompute the forward pass (folded operands; r = sigmoid form of tanh) ----
         f4 r[L][2];
@@ -240,17 +261,29 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
             f4 dy;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float g = gy[mo][j];
+                float g = gy[mo][j];
                 if (INV) {  // y' = (y - t) e^-s
                     const float em = __builtin_amdgcn_exp2f(-sv[j]);
+                    const float yo = (y[mo][j] - tt[j]) * em;
+                    if (finalize) g = -glp * yo;
                     dy[j] = g * em;
                     dout[0][mo][j] = -dy[j];
-                    dout[1][mo][j] = __builtin_fmaf(-g, (y[mo][j] - tt[j]) * em, gl);
+                    dout[1][mo][j] = __builtin_fmaf(-g, yo, gl);
                 } else {    // y' = t + y e^s
                     const float e = __builtin_amdgcn_exp2f(sv[j]);
                     dy[j] = g * e;
                     dout[0][mo][j] = g;
                     dout[1][mo][j] = __builtin_fmaf(g * y[mo][j], e, gl);
+                }
+            }
+            // back through the fold: g wrt the saved input, and the fold-constant gradients
+            {
+                const f4 ay = *reinterpret_cast<const f4*>(cfy + 16 * mo);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dAy[mo][j] = __builtin_fmaf(dy[j], ys[mo][j], dAy[mo][j]);
+                    dBy[mo][j] += dy[j];
+                    dy[j] *= ay[j];
                 }
             }
             if (row_ok) *reinterpret_cast<f4*>(gzb + row * D + 4 * q + 16 * mo + t_off) = dy;
@@ -325,6 +358,16 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
                 for (int j = 0; j < 4; ++j) dx[mm] = mfma4(wb[j], da[j], dx[mm]);
             }
         }
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            const f4 ax = *reinterpret_cast<const f4*>(cfx + 16 * mm);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dAx[mm][j] = __builtin_fmaf(dx[mm][j], xs[mm][j], dAx[mm][j]);
+                dBx[mm][j] += dx[mm][j];
+                dx[mm][j] *= ax[j];
+            }
+        }
         if (row_ok) {
 #pragma unroll
             for (int mm = 0; mm < HT; ++mm)
@@ -339,7 +382,7 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
     float* gacc = lds;               // reuse the image area: P floats
     const int U = a.U;
     const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
-    for (int i = threadIdx.x; i < P; i += 256) gacc[i] = 0.f;
+    for (int i = threadIdx.x; i < P + 2 * D; i += 256) gacc[i] = 0.f;
     __syncthreads();
     const int c = lane & 15;  // column of the dW accumulators; rows are 4q + j
     auto red16 = [&](float v) -> float {  // sum over the 16 sample lanes of a q-group
@@ -416,9 +459,30 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
                 }
             }
     }
+    if (a.g_fold) {  // fold-constant gradients: reduce over the 16 sample lanes, then LDS
+        float* gf = gacc + P;  // [dA (D) | dB (D)], zeroed with the rest below P? no: zero it here first
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ax = red16(dAx[mm][j]), bx = red16(dBx[mm][j]);
+                const float ay = red16(dAy[mm][j]), by = red16(dBy[mm][j]);
+                if (s == 0) {
+                    const int fx = c_off + 16 * mm + 4 * q + j, fy = t_off + 16 * mm + 4 * q + j;
+                    atomicAdd(gf + fx, ax);
+                    atomicAdd(gf + D + fx, bx);
+                    atomicAdd(gf + fy, ay);
+                    atomicAdd(gf + D + fy, by);
+                }
+            }
+    }
     __syncthreads();
     float* gout = a.g_params + mp * a.gpstride;
     for (int i = threadIdx.x; i < P; i += 256) atomicAdd(gout + i, gacc[i]);
+    if (a.g_fold) {
+        float* gfo = a.g_fold + mp * a.fold_stride;
+        for (int i = threadIdx.x; i < 2 * D; i += 256) atomicAdd(gfo + i, gacc[P + i]);
+    }
 }
 
 template <int H, int L>
@@ -432,7 +496,13 @@ int launch_coupling_backward_mfma(const float* z, const float* params, const flo
                                   int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
                                   int64_t gpstride, hipStream_t st) {
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "coupling_backward_mfma: D=%d L=%d U=%d", D, L, U);
-    BwdArgs a{z, params, g_zout, g_ld, g_z, g_params, M, Mp, N, pstride, gpstride, U, upper};
+    BwdArgs a{z, params, g_zout, g_ld, g_z, g_params, M, Mp, N, pstride, gpstride, U, upper,
+              nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f};
+    return launch_coupling_backward_mfma_args(a, D, L, inverse, st);
+}
+
+int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st) {
+    const int64_t M = a.M, N = a.N;
     const int64_t ntiles = (N + 15) / 16;
     int64_t bx = (ntiles + 3) / 4;
     int64_t cap = 512 / M;  // persistent grid (2 workgroups per CU): each ends with one atomic per parameter

@@ -62,6 +62,57 @@ flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_
 }
 
 // ---------------------------------------------------------------------------
+// Backward of the fold (inverse chain): from the accumulated gradients of the fold constants
+//   A = alpha_bn / e^a,  B = mu_bn - shift * A        (layers with an Affine in front: c odd)
+// to the Affine parameters:  g_a = -A dA + shift A dB,  g_shift = -A dB,
+// plus the constant log-det term of log_prob = ... - ldc, ldc = sum_f a_f - sum log alpha_bn:
+//   g_a -= sum over the samples of g_log_prob.
+// g_fold: (Mp, 2S, 2, D).  One workgroup per parameter row.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+flow_fold_backward_kernel(const float* __restrict__ params, const float* __restrict__ bn_alpha,
+                          const float* __restrict__ g_fold, const float* __restrict__ g_lp,
+                          float* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L,
+                          int U, int64_t pstride, int64_t gpstride) {
+    __shared__ float red[256];
+    const int64_t mp = blockIdx.x;
+    // sum of g_log_prob over the samples that use this parameter row
+    const int64_t cnt = (Mp == 1 ? M : 1) * N;
+    const float* gl = g_lp + (Mp == 1 ? 0 : mp * N);
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) acc += gl[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float sum_glp = red[0];
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const float* p = params + mp * pstride;
+    float* gp = g_params + mp * gpstride;
+    for (int idx = threadIdx.x; idx < S * D; idx += 256) {
+        const int st = idx / D, d = idx - st * D;
+        const int c = 2 * st + 1;
+        const int64_t off = st * fl.stage + fl.p_up + fl.p_low;
+        const float a = p[off + d], shift = p[off + D + d];
+        const float A = bn_alpha[c * D + d] / expf(a);
+        const float* gf = g_fold + ((mp * 2 * S + c) * 2) * D;
+        const float dA = gf[d], dB = gf[D + d];
+        atomicAdd(gp + off + d, -A * dA + shift * A * dB - sum_glp);
+        atomicAdd(gp + off + D + d, -A * dB);
+    }
+}
+
+int launch_flow_fold_backward(const float* params, const float* bn_alpha, const float* g_fold, const float* g_lp,
+                              float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U,
+                              int64_t pstride, int64_t gpstride, hipStream_t st) {
+    hipLaunchKernelGGL(flow_fold_backward_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_alpha, g_fold,
+                       g_lp, g_params, M, Mp, N, D, S, L, U, pstride, gpstride);
+    return check_launch("flow_fold_backward");
+}
+
+// ---------------------------------------------------------------------------
 // Build every layer's MFMA operand image once per call (one wave per (layer, context)):
 // the gather from the packed parameter row, the activation folding and the column sums
 // happen here, so the hot kernels start from coalesced float4 loads of a lane-ordered

@@ -108,6 +108,9 @@ int launch_wide_images(const float* params, float* images, int64_t Mp, int D, in
 // Per-call preparation for the flow-level chains: fold BN/Affine constants (fold: (Mp, 2S, 2, D),
 // ldc: (Mp)) and build the lane-ordered MFMA operand images (Mp, 2S, mfma_image_floats(D, L)).
 int64_t mfma_image_floats(int D, int L);
+int launch_flow_fold_backward(const float* params, const float* bn_alpha, const float* g_fold, const float* g_lp,
+                              float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U,
+                              int64_t pstride, int64_t gpstride, hipStream_t st);
 int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
                      float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
                      int64_t pstride, int inverse, hipStream_t st);
@@ -135,6 +138,26 @@ int launch_coupling_backward(int dtype, const void* z, const void* params, const
                              const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp,
                              int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
                              int64_t gpstride, hipStream_t st);
+// arguments of the MFMA backward kernel (coupling_bwd_mfma.hip)
+struct BwdArgs {
+    const float* z;
+    const float* params;
+    const float* g_zout;
+    const float* g_ld;
+    float* g_z;
+    float* g_params;
+    int64_t M, Mp, N, pstride, gpstride;
+    int U, upper;
+    // flow-level extensions (all optional / neutral by default):
+    const float* image;   // prepared forward operand image of this layer (per mp: image_stride floats)
+    int64_t image_stride;
+    const float* fold;    // [A (D) | B (D)] applied to the saved input before the layer (per mp: fold_stride)
+    float* g_fold;        // accumulates [dA (D) | dB (D)] (per mp: fold_stride)
+    int64_t fold_stride;
+    const float* g_lp;    // finalize: upstream gradient is that of log_prob = -|out|^2/2 - ... (M,N)
+    float ld_scale;       // gradient w.r.t. sum(s) = ld_scale * g_ld[row]
+};
+int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);
 int launch_coupling_backward_mfma(const float* z, const float* params, const float* g_zout,
                                   const float* g_ld, float* g_z, float* g_params, int64_t M, int64_t Mp,
                                   int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,

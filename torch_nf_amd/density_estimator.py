@@ -292,6 +292,14 @@ class NormFlow(DensityEstimator):
             lp, _, _ = ops.flow_log_prob_raw(z, params, mean, alpha, self.D, self.num_stages,
                                              self.num_layers, self.num_units, self.fusion)
             return lp
+        if (self.arch_type == "coupling" and z.dtype == torch.float32 and params.dtype == torch.float32
+                and z.dim() == 3 and z.size(0) == max(z.size(0), params.size(0))
+                and ops.flow_train_supported(z.size(0), params.size(0), z.size(1), self.D, self.num_stages,
+                                             self.num_layers, self.num_units)):
+            # training: fused per-layer kernels forward, MFMA backward kernels (BatchNorm stats constant)
+            mean, alpha = self._bn_stats(_lib.require_device())
+            return ops.flow_log_prob_train(z, params, mean, alpha, self.D, self.num_stages, self.num_layers,
+                                           self.num_units)
         z0, sum_log_det = self.inverse_and_log_det(z, params)
         log_q = torch.sum(-(z0 ** 2), axis=2) / 2.0 - self.D * np.log(np.sqrt(2.0 * np.pi))
         return log_q - sum_log_det

@@ -364,3 +364,55 @@ def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.F
     if home != dev:
         z_out, sld = z_out.to(home), sld.to(home)
     return z_out, sld
+
+
+# ---------------------------------------------------------------------------
+# flow level, with autograd: log_prob through one fused kernel per layer, backward through one
+# MFMA backward kernel per layer (tnf_flow_log_prob_fwd_f32 / _bwd_f32)
+# ---------------------------------------------------------------------------
+def flow_train_supported(M, Mp, N, D, S, L, U):
+    return Mp in (1, M) and N >= 32 and lib.tnf_flow_train_workspace_bytes(M, Mp, max(N, 1), D, S, L, U) >= 0
+
+
+class _FlowLogProbFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, params, bn_mean, bn_alpha, D, S, L, U):
+        dev = _lib.require_device()
+        zc = _stage(z.detach(), dev)
+        pc, pstride = _rows(params.detach(), dev)
+        mean_c, alpha_c = _stats(bn_mean, dev), _stats(bn_alpha, dev)
+        M, N = zc.shape[0], zc.shape[1]
+        Mp = pc.shape[0]
+        lp = torch.empty((M, N), dtype=torch.float32, device=dev)
+        states = torch.empty((2 * S - 1, M, N, D), dtype=torch.float32, device=dev)
+        ws_bytes = check(lib.tnf_flow_train_workspace_bytes(M, Mp, N, D, S, L, U))
+        ws = _workspace(ws_bytes, dev)
+        check(lib.tnf_flow_log_prob_fwd_f32(zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+                                            lp.data_ptr(), states.data_ptr(), M, Mp, N, D, S, L, U, pstride,
+                                            ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        ctx.save_for_backward(zc, pc, mean_c, alpha_c, states)
+        ctx.cfg = (D, S, L, U, pstride, z.device, params.device, tuple(params.shape))
+        return lp if z.device == dev else lp.to(z.device)
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        zc, pc, mean_c, alpha_c, states = ctx.saved_tensors
+        D, S, L, U, pstride, z_home, p_home, p_shape = ctx.cfg
+        dev = zc.device
+        M, N = zc.shape[0], zc.shape[1]
+        Mp = pc.shape[0]
+        g = _stage(g_lp.float(), dev)
+        gz = torch.empty_like(zc)
+        gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+        ws_bytes = check(lib.tnf_flow_train_workspace_bytes(M, Mp, N, D, S, L, U))
+        ws = _workspace(ws_bytes, dev)
+        check(lib.tnf_flow_log_prob_bwd_f32(zc.data_ptr(), states.data_ptr(), pc.data_ptr(), mean_c.data_ptr(),
+                                            alpha_c.data_ptr(), g.data_ptr(), gz.data_ptr(), gp.data_ptr(), M, Mp,
+                                            N, D, S, L, U, pstride, gp.shape[1], ws.data_ptr(), ws.numel(),
+                                            _lib.stream_ptr()))
+        return (gz if z_home == dev else gz.to(z_home)), (gp if p_home == dev else gp.to(p_home)), None, None, \
+            None, None, None, None
+
+
+def flow_log_prob_train(z, params, bn_mean, bn_alpha, D, S, L, U):
+    return _FlowLogProbFn.apply(z, params, bn_mean, bn_alpha, D, S, L, U)
