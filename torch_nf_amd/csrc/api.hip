@@ -380,7 +380,8 @@ static TrainWs train_ws(int64_t M, int64_t Mp, int64_t N, int D, int S, int L) {
     w.ldc = round16(Mp * 2 * S * 2 * D * (int64_t)sizeof(float));
     w.images = w.ldc + round16(Mp * (int64_t)sizeof(float));
     w.gfold = w.images + round16(Mp * 2 * S * mfma_image_floats(D, L) * (int64_t)sizeof(float));
-    w.ldbuf = w.gfold + round16(Mp * 2 * S * 2 * D * (int64_t)sizeof(float));
+    // g_fold (Mp, 2S, 2, D) followed by the per-row sums of g_log_prob (Mp): zeroed together
+    w.ldbuf = w.gfold + round16((Mp * 2 * S * 2 * D + Mp) * (int64_t)sizeof(float));
     w.gbuf = w.ldbuf + round16(M * N * (int64_t)sizeof(float));
     w.total = w.gbuf + 2 * round16(M * N * D * (int64_t)sizeof(float));
     return w;
@@ -481,7 +482,8 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
                       reinterpret_cast<float*>(wsb + w.gbuf + round16(M * N * D * (int64_t)sizeof(float)))};
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 1, st);
     if (rc) return rc;
-    if (hipMemsetAsync(gfold, 0, (size_t)(M_p * 2 * S * 2 * D) * sizeof(float), st) != hipSuccess)
+    float* glp_sum = gfold + M_p * 2 * S * 2 * D;
+    if (hipMemsetAsync(gfold, 0, (size_t)(M_p * 2 * S * 2 * D + M_p) * sizeof(float), st) != hipSuccess)
         return fail(TNF_ELAUNCH, "tnf_flow_log_prob_bwd_f32: memset failed");
     const FlowLayout fl = flow_layout(D, S, L, U);
     const int64_t img_floats = mfma_image_floats(D, L);
@@ -507,11 +509,12 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
         a.g_fold = gfold + (int64_t)c * 2 * D;
         a.fold_stride = (int64_t)nl * 2 * D;
         a.g_lp = (c == 0) ? g_log_prob : nullptr;
+        a.glp_sum = glp_sum;
         rc = launch_coupling_backward_mfma_args(a, D, L, 1, st);
         if (rc) return rc;
     }
-    return launch_flow_fold_backward(params, bn_alpha, gfold, g_log_prob, g_params, M, M_p, N, D, S, L, U, pstride,
-                                     gpstride, st);
+    return launch_flow_fold_backward(params, bn_alpha, gfold, glp_sum, g_params, M_p, D, S, L, U, pstride, gpstride,
+                                     st);
 }
 
 int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,

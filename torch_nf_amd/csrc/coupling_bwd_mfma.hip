@@ -185,6 +185,7 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
         for (int l = 0; l < LH; ++l) { dWh[l][net] = zero; dbh[l][net] = zero; }
     }
 
+    float glp_acc = 0.f;
     const int64_t ntiles = (a.N + 15) >> 4;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t row = tile * 16 + s;
@@ -192,6 +193,7 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
         const int64_t rowc = row_ok ? row : a.N - 1;
         f4 x[HT], y[HT], xs[HT], ys[HT], gx[HT], gy[HT];
         const float glp = (finalize && row_ok) ? glpb[rowc] : 0.f;
+        if (q == 0) glp_acc += glp;
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
             const float* zr = zb + rowc * D + 4 * q + 16 * mm;
@@ -459,6 +461,10 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
                 }
             }
     }
+    if (finalize && a.glp_sum) {
+        const float tot = red16(glp_acc);
+        if (lane == 0) atomicAdd(a.glp_sum + mp, tot);
+    }
     if (a.g_fold) {  // fold-constant gradients: reduce over the 16 sample lanes, then LDS
         float* gf = gacc + P;  // [dA (D) | dB (D)], zeroed with the rest below P? no: zero it here first
 #pragma unroll
@@ -497,7 +503,7 @@ int launch_coupling_backward_mfma(const float* z, const float* params, const flo
                                   int64_t gpstride, hipStream_t st) {
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "coupling_backward_mfma: D=%d L=%d U=%d", D, L, U);
     BwdArgs a{z, params, g_zout, g_ld, g_z, g_params, M, Mp, N, pstride, gpstride, U, upper,
-              nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f};
+              nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, nullptr};
     return launch_coupling_backward_mfma_args(a, D, L, inverse, st);
 }
 

@@ -71,23 +71,11 @@ flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 flow_fold_backward_kernel(const float* __restrict__ params, const float* __restrict__ bn_alpha,
-                          const float* __restrict__ g_fold, const float* __restrict__ g_lp,
-                          float* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L,
-                          int U, int64_t pstride, int64_t gpstride) {
-    __shared__ float red[256];
+                          const float* __restrict__ g_fold, const float* __restrict__ glp_sum,
+                          float* __restrict__ g_params, int D, int S, int L, int U, int64_t pstride,
+                          int64_t gpstride) {
     const int64_t mp = blockIdx.x;
-    // sum of g_log_prob over the samples that use this parameter row
-    const int64_t cnt = (Mp == 1 ? M : 1) * N;
-    const float* gl = g_lp + (Mp == 1 ? 0 : mp * N);
-    float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < cnt; i += 256) acc += gl[i];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    const float sum_glp = red[0];
+    const float sum_glp = glp_sum[mp];  // sum of g_log_prob over the samples that use this row
     const FlowLayout fl = flow_layout(D, S, L, U);
     const float* p = params + mp * pstride;
     float* gp = g_params + mp * gpstride;
@@ -104,11 +92,11 @@ flow_fold_backward_kernel(const float* __restrict__ params, const float* __restr
     }
 }
 
-int launch_flow_fold_backward(const float* params, const float* bn_alpha, const float* g_fold, const float* g_lp,
-                              float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U,
-                              int64_t pstride, int64_t gpstride, hipStream_t st) {
+int launch_flow_fold_backward(const float* params, const float* bn_alpha, const float* g_fold, const float* glp_sum,
+                              float* g_params, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
+                              int64_t gpstride, hipStream_t st) {
     hipLaunchKernelGGL(flow_fold_backward_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_alpha, g_fold,
-                       g_lp, g_params, M, Mp, N, D, S, L, U, pstride, gpstride);
+                       glp_sum, g_params, D, S, L, U, pstride, gpstride);
     return check_launch("flow_fold_backward");
 }
 

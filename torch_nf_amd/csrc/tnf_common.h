@@ -108,9 +108,9 @@ int launch_wide_images(const float* params, float* images, int64_t Mp, int D, in
 // Per-call preparation for the flow-level chains: fold BN/Affine constants (fold: (Mp, 2S, 2, D),
 // ldc: (Mp)) and build the lane-ordered MFMA operand images (Mp, 2S, mfma_image_floats(D, L)).
 int64_t mfma_image_floats(int D, int L);
-int launch_flow_fold_backward(const float* params, const float* bn_alpha, const float* g_fold, const float* g_lp,
-                              float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U,
-                              int64_t pstride, int64_t gpstride, hipStream_t st);
+int launch_flow_fold_backward(const float* params, const float* bn_alpha, const float* g_fold, const float* glp_sum,
+                              float* g_params, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
+                              int64_t gpstride, hipStream_t st);
 int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
                      float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
                      int64_t pstride, int inverse, hipStream_t st);
@@ -156,6 +156,7 @@ struct BwdArgs {
     int64_t fold_stride;
     const float* g_lp;    // finalize: upstream gradient is that of log_prob = -|out|^2/2 - ... (M,N)
     float ld_scale;       // gradient w.r.t. sum(s) = ld_scale * g_ld[row]
+    float* glp_sum;       // finalize: accumulates sum over the samples of g_lp (per mp), for the constant log-det
 };
 int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);
 int launch_coupling_backward_mfma(const float* z, const float* params, const float* g_zout,
