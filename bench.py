@@ -179,6 +179,35 @@ def main():
     # the per-layer chain (k = 8), outside the timed region
     wall_l, ev_l, lp_l = run(L_.FUSE_LAYER, max(5, args.steps // 2), 2)
 
+    # BASELINE configs[3], per-GPU share: one training step (loss = -mean log_prob, backward, Adam)
+    # on 2^19 samples; outside the timed region.  With N GPUs the only collective is the gradient.
+    train_ms = None
+    if rank == 0 or world > 1:
+        n_tr = 1 << 19
+        p_train = nf.params.detach().clone().requires_grad_()
+        nf_params_saved, nf.params = nf.params, p_train
+        opt = torch.optim.Adam([p_train], lr=1e-4)
+        z_tr = z[:, :n_tr].contiguous()
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            loss = -nf.log_prob(z_tr).mean()
+            loss.backward()
+            if world > 1:
+                from torch_nf_amd.distributed import allreduce_gradients
+                allreduce_gradients([p_train], average=True)
+            opt.step()
+
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            train_step()
+        torch.cuda.synchronize()
+        train_ms = (time.perf_counter() - t0) / 5 * 1e3
+        nf.params = nf_params_saved
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -243,6 +272,11 @@ def main():
                    "sharding": "samples, no collective in the timed region"},
         "roofline": roofline,
         "layer_chain": layer_chain,
+        "train_step": None if train_ms is None else {
+            "ms": round(train_ms, 3), "samples_per_gpu": 1 << 19,
+            "value": round((1 << 19) * world / (train_ms * 1e-3) / 1e6, 1), "unit": "M samples/s",
+            "what": "loss = -mean(log_prob); backward (MFMA backward kernels); "
+                    + ("RCCL all-reduce of the flat gradient; " if world > 1 else "") + "Adam step"},
     }
 
     if not args.no_cpu_baseline and world == 1:
