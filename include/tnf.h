@@ -150,6 +150,23 @@ int tnf_bn_batch_backward_f32(const float* z_norm, const float* g_z_out, const f
                               const float* alpha, float* g_z, int64_t rows, int32_t D, void* workspace,
                               int64_t workspace_bytes, void* stream);
 
+/* ---- MAF, the bijector of NormFlow's default arch_type "AR" (bijectors.py:597-806) ----------
+ * Twin masked MLPs without biases; params = [W_mu0 | W_alpha0 | ... | W_mu_last | W_alpha_last]
+ * (bijectors.py:698-740), W row-major [in][out]; `masks` = the binary matrices Ms of
+ * MAF._get_masks (bijectors.py:663-696) concatenated in layer order (D*U, (L-1) x U*U, U*D
+ * elements of `dtype`), shared by all parameter rows.
+ * inverse != 0: MAF.inverse_and_log_det (one pass, :758-764); inverse == 0:
+ * MAF.forward_and_log_det (D-1 sequential passes, :742-756).  log_det (M,N) = sum(f_alpha).
+ * tnf_maf_backward differentiates the INVERSE direction (what log_prob training needs). */
+int64_t tnf_maf_num_params(int32_t D, int32_t num_layers, int32_t num_units);
+int tnf_maf(int32_t dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
+            int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_layers, int32_t num_units,
+            int32_t inverse, int64_t params_row_stride, void* stream);
+int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
+                     const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N,
+                     int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
+                     int64_t g_params_row_stride, void* stream);
+
 /* Base density of NormFlow.forward, float64 like the reference's numpy expression
  * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as
  * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)) in float64.  omega (rows, D) of `dtype` (TNF_F64 for

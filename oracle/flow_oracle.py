@@ -44,6 +44,11 @@ __all__ = [
     "flow_log_prob",
     "flow_forward",
     "base_log_density_f64",
+    "maf_masks",
+    "maf_num_params",
+    "maf",
+    "ar_flow_log_prob",
+    "ar_flow_forward",
 ]
 
 
@@ -241,3 +246,98 @@ def flow_forward(omega, params, D, num_stages, num_layers, num_units, bn_stats=N
             bn_i += 1
         log_q = log_q - ld
     return z, log_q, new_stats
+
+
+# --------------------------------------------------------------------------
+# MAF (masked autoregressive flow) -- bijectors.py:597-806, arch_type "AR"
+# --------------------------------------------------------------------------
+def maf_masks(D, num_layers, num_units, fwd_fac=True, rng=np.random):
+    """Degree vectors `ms` and binary masks `Ms` drawn exactly like MAF._get_masks
+    (bijectors.py:663-696): hidden degrees from rng.randint(1, D, (K,)), layer masks
+    M[k_prev, k] = m_prev[k_prev] <= m[k], final mask strict (<).  fwd_fac=False keeps the
+    reference's arange(D, -1, -1) (D+1 entries, the last one unused)."""
+    ms, Ms = [], []
+    k_prev = D
+    m_prev = np.arange(1, D + 1) if fwd_fac else np.arange(D, -1, -1)
+    for _ in range(num_layers):
+        m = rng.randint(1, D, (num_units,))
+        Ms.append((m_prev[:k_prev, None] <= m[None, :]).astype(np.float32))
+        ms.append(m)
+        k_prev, m_prev = num_units, m
+    m = np.arange(1, D + 1) if fwd_fac else np.arange(D, -1, -1)
+    Ms.append((m_prev[:k_prev, None] < m[None, :D]).astype(np.float32))
+    ms.append(m)
+    return ms, Ms
+
+
+def maf_num_params(D, num_layers, num_units):
+    """bijectors.py:796-806."""
+    return 2 * (2 * D * num_units + (num_layers - 1) * num_units ** 2)
+
+
+def _maf_net(z, params, D, L, U, Ms):
+    """(f_mu, f_alpha): twin masked MLPs without biases, tanh on the hidden layers
+    (bijectors.py:702-790).  params = [W_mu0 | W_alpha0 | ... | W_mu_last | W_alpha_last]."""
+    dims = [D] + [U] * L + [D]
+    off = 0
+    f_mu, f_alpha = z, z
+    for i in range(L + 1):
+        d_in, d_out = dims[i], dims[i + 1]
+        n = d_in * d_out
+        mask = torch.as_tensor(Ms[i])[None, :, :]
+        w_mu = mask * params[:, off:off + n].view(-1, d_in, d_out)
+        off += n
+        w_alpha = mask * params[:, off:off + n].view(-1, d_in, d_out)
+        off += n
+        f_mu = torch.matmul(f_mu, w_mu)
+        f_alpha = torch.matmul(f_alpha, w_alpha)
+        if i < L:
+            f_mu = torch.tanh(f_mu)
+            f_alpha = torch.tanh(f_alpha)
+    return f_mu, f_alpha
+
+
+def maf(z, params, D, num_layers, num_units, Ms, inverse):
+    """MAF.forward_and_log_det (D-1 passes, bijectors.py:742-756) / inverse_and_log_det
+    (one pass, :758-764)."""
+    if inverse:
+        f_mu, f_alpha = _maf_net(z, params, D, num_layers, num_units, Ms)
+        return (z - f_mu) / torch.exp(f_alpha), torch.sum(f_alpha, dim=2)
+    u = z
+    for _ in range(D - 1):
+        f_mu, f_alpha = _maf_net(z, params, D, num_layers, num_units, Ms)
+        z = u * torch.exp(f_alpha) + f_mu
+    return z, torch.sum(f_alpha, axis=2)
+
+
+def ar_flow_log_prob(z, params, D, num_layers, num_units, Ms, bn_stat):
+    """NormFlow(arch_type="AR").log_prob: stack [MAF, BatchNorm, Affine]
+    (density_estimator.py:271-274, 390-416)."""
+    n_maf = maf_num_params(D, num_layers, num_units)
+    sum_log_det = torch.zeros((z.shape[0], z.shape[1]))
+    z, ld = affine(z, params[:, n_maf:n_maf + 2 * D], D, True)
+    sum_log_det += ld
+    z, ld = bn_inverse(z, bn_stat[0], bn_stat[1])
+    sum_log_det += ld
+    z, ld = maf(z, params[:, :n_maf], D, num_layers, num_units, Ms, True)
+    sum_log_det += ld
+    log_q = torch.sum(-(z ** 2), axis=2) / 2.0 - D * np.log(np.sqrt(2.0 * np.pi))
+    return log_q - sum_log_det
+
+
+def ar_flow_forward(omega, params, D, num_layers, num_units, Ms, bn_stat=None):
+    """NormFlow(arch_type="AR").forward with the host draw injected."""
+    n_maf = maf_num_params(D, num_layers, num_units)
+    z = torch.tensor(omega).float()
+    log_q = torch.tensor(base_log_density_f64(omega))
+    z, ld = maf(z, params[:, :n_maf], D, num_layers, num_units, Ms, False)
+    log_q = log_q - ld
+    if bn_stat is None:
+        z, ld, mean, alpha = bn_forward_batch(z)
+    else:
+        mean, alpha = bn_stat
+        z, ld = bn_forward_frozen(z, mean, alpha)
+    log_q = log_q - ld
+    z, ld = affine(z, params[:, n_maf:n_maf + 2 * D], D, False)
+    log_q = log_q - ld
+    return z, log_q, (mean, alpha)

@@ -282,11 +282,91 @@ def gen_cde():
     print("cde: %d cases" % len(meta))
 
 
+# ---------------------------------------------------------------------------
+# 5. MAF and NormFlow('AR')
+# ---------------------------------------------------------------------------
+def gen_maf():
+    out = {}
+    meta = []
+    cases = [(4, 2, 15, True, 3, 3, 7, "f64"), (5, 1, 20, True, 2, 2, 9, "f64"), (4, 3, 15, False, 2, 2, 5, "f64"),
+             (8, 2, 20, True, 1, 1, 65, "f32"), (6, 2, 15, True, 3, 1, 11, "f32"), (16, 2, 32, True, 1, 1, 33, "f32")]
+    for ci, (D, L, U, fwd_fac, Mz, Mp, N, dt) in enumerate(cases):
+        np.random.seed(200 + ci)
+        st = np.random.get_state()
+        layer = rb.MAF(D, L, U, fwd_fac=fwd_fac)
+        np.random.set_state(st)
+        ms, Ms = orc.maf_masks(D, L, U, fwd_fac)  # same RNG stream -> same masks
+        assert all(np.array_equal(a, b) for a, b in zip(ms, layer.ms))
+        assert all(np.array_equal(a, b[0].numpy()) for a, b in zip(Ms, layer.Ms))
+        n_par = layer.count_num_params()
+        assert n_par == orc.maf_num_params(D, L, U)
+        rng = np.random.RandomState(300 + ci)
+        params = torch.tensor(rng.normal(0.0, 0.3, (Mp, n_par))).to(tdtype(dt))
+        z = torch.tensor(rng.normal(0.0, 1.0, (Mz, N, D))).to(tdtype(dt))
+        if dt == "f64":
+            layer.Ms = [m.double() for m in layer.Ms]  # the reference's float32 masks promote anyway
+        zf, ldf = layer.forward_and_log_det(z, params)
+        zi, ldi = layer.inverse_and_log_det(z, params)
+        ozf, oldf = orc.maf(z, params, D, L, U, Ms, False)
+        ozi, oldi = orc.maf(z, params, D, L, U, Ms, True)
+        assert same(zf, ozf) and same(ldf, oldf) and same(zi, ozi) and same(ldi, oldi), ci
+        k = "m%02d_" % ci
+        out[k + "z"], out[k + "params"] = npy(z), npy(params)
+        for i, m in enumerate(ms):
+            out[k + "ms%d" % i] = np.asarray(m)
+        out[k + "z_fwd"], out[k + "ld_fwd"] = npy(zf), npy(ldf)
+        out[k + "z_inv"], out[k + "ld_inv"] = npy(zi), npy(ldi)
+        meta.append([D, L, U, int(fwd_fac), Mz, Mp, N, 0 if dt == "f32" else 1])
+    out["meta"] = np.array(meta, dtype=np.int64)
+
+    # NormFlow(arch_type="AR"): forward (batch stats), frozen forward, log_prob, gradients
+    fmeta = []
+    for ci, (D, L, U, N) in enumerate([(4, 2, 20, 50), (8, 2, 15, 129), (16, 1, 32, 64)]):
+        np.random.seed(400 + ci)
+        torch.manual_seed(400 + ci)
+        st = np.random.get_state()
+        nf = rde.NormFlow(D, False, "AR", 1, L, U)
+        np.random.set_state(st)
+        ms, Ms = orc.maf_masks(D, L, U, True)
+        nf.params = torch.tensor(np.random.normal(0.0, 0.2, (1, nf.D_params))).float().requires_grad_()
+        params = nf.params.detach()
+        st = np.random.get_state()
+        omega = np.random.normal(0.0, 1.0, (1, N, D))
+        np.random.set_state(st)
+        z, log_q = nf(N)
+        bn = nf.bijectors[1]
+        stat = (bn.get_last_mean().detach(), bn.get_last_alpha().detach())
+        oz, olq, ostat = orc.ar_flow_forward(omega, params, D, L, U, Ms, None)
+        assert same(z.detach(), oz) and same(log_q.detach(), olq) and same(stat[0], ostat[0].detach())
+        z_test = torch.tensor(np.random.normal(0.0, 1.0, (1, N, D))).float()
+        lp = nf.log_prob(z_test)
+        olp = orc.ar_flow_log_prob(z_test, params, D, L, U, Ms, stat)
+        assert same(lp.detach(), olp)
+        zt = z_test.clone().requires_grad_()
+        p = params.clone().requires_grad_()
+        nf.params = p
+        loss = -torch.mean(nf.log_prob(zt))
+        loss.backward()
+        k = "n%02d_" % ci
+        out[k + "params"], out[k + "omega"] = npy(params), omega
+        for i, m in enumerate(ms):
+            out[k + "ms%d" % i] = np.asarray(m)
+        out[k + "z_fwd"], out[k + "logq_fwd"] = npy(z), npy(log_q)
+        out[k + "bn_mean"], out[k + "bn_alpha"] = npy(stat[0]), npy(stat[1])
+        out[k + "z_test"], out[k + "log_prob"] = npy(z_test), npy(lp)
+        out[k + "loss"], out[k + "grad_params"], out[k + "grad_z"] = npy(loss), npy(p.grad), npy(zt.grad)
+        fmeta.append([D, L, U, N])
+    out["flow_meta"] = np.array(fmeta, dtype=np.int64)
+    np.savez(os.path.join(OUT, "maf.npz"), **out)
+    print("maf: %d bijector cases, %d AR flows" % (len(meta), len(fmeta)))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_coupling()
-    gen_affine_bn()
-    gen_flow()
-    gen_cde()
+    only = os.environ.get("GOLDEN_ONLY")  # e.g. GOLDEN_ONLY=maf regenerates one fixture file
+    for name, fn in (("coupling", gen_coupling), ("affine_bn", gen_affine_bn), ("flow", gen_flow), ("cde", gen_cde),
+                     ("maf", gen_maf)):
+        if only is None or only == name:
+            fn()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("total fixture bytes: %d" % tot)

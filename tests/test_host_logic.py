@@ -125,9 +125,50 @@ def test_normflow_validation_and_layout(capsys, oracle):
         assert nf.D_params == want == oracle.flow_num_params(D, S, 2, 15)
         assert nf.params.shape == (1, want) and nf.params.requires_grad and nf.params.is_leaf
     assert type(tnf.NormFlow(4, False, "affine").bijectors[0]).__name__ == "Affine"
-    # out-of-scope architectures fail loudly instead of silently computing something else
+    # the reference's default architecture: MAF, BatchNorm, Affine (density_estimator.py:271-274)
+    nf = tnf.NormFlow(4, False, num_layers=2, num_units=20, device="cpu")
+    assert nf.arch_type == "AR" and [type(b).__name__ for b in nf.bijectors] == ["MAF", "BatchNorm", "Affine"]
+    assert nf.D_params == oracle.maf_num_params(4, 2, 20) + 8
+    # support layers are outside this build: loud, not silent
     with raises(NotImplementedError):
-        tnf.NormFlow(4, False, "AR")
+        tnf.NormFlow(4, False, "coupling", 1, 2, 20, tnf.Bijector(4))
+
+
+def test_maf_validation_and_masks(capsys, oracle):
+    """MAF constructor (reference tests/test_bijectors.py:125-160) and mask RNG parity: the same
+    np.random state yields the degree vectors / masks of MAF._get_masks (bijectors.py:663-696)."""
+    maf = tnf.MAF(4, 2, 20)
+    assert (maf.name, maf.D, maf.num_layers, maf.num_units, maf.fwd_fac) == ("MAF", 4, 2, 20, True)
+    assert maf.count_num_params() == oracle.maf_num_params(4, 2, 20) == 2 * (2 * 4 * 20 + 400)
+    m2 = tnf.MAF(4, 6, 2000)
+    assert m2.num_layers == 5 and m2.num_units == 1000
+    assert tnf.MAF(4, 1, 3).num_units == 5
+    out = capsys.readouterr().out
+    assert "Warning: MAF.num_layers set to maximum of 5 (received 6)." in out
+    assert "Warning: num_units set to minimum of 15 (received 3)." in out  # the reference's wording
+    with raises(TypeError):
+        tnf.MAF(4, "foo", 10)
+    with raises(ValueError):
+        tnf.MAF(4, -1, 10)
+    with raises(TypeError):
+        tnf.MAF(4, 2, "foo")
+    with raises(TypeError, match="MAF argument fwd_fac must be bool not str."):
+        tnf.MAF(4, 2, 10, "foo")
+    for D, L, U, fwd in [(4, 2, 15, True), (7, 3, 20, True), (5, 1, 9, False)]:
+        np.random.seed(7)
+        maf = tnf.MAF(D, L, U, fwd_fac=fwd)
+        np.random.seed(7)
+        ms, Ms = oracle.maf_masks(D, L, U, fwd)
+        assert len(maf.ms) == L + 1 and all(np.array_equal(a, b) for a, b in zip(maf.ms, ms))
+        assert all(np.array_equal(a[0].numpy(), b) for a, b in zip(maf.Ms, Ms))
+        assert [tuple(M.shape) for M in maf.Ms] == [(1, D, U)] + [(1, U, U)] * (L - 1) + [(1, U, D)]
+    # autoregressive property of the composed masks: output d depends only on inputs with degree < d
+    np.random.seed(1)
+    maf = tnf.MAF(6, 2, 30)
+    conn = maf.Ms[0][0]
+    for M in maf.Ms[1:]:
+        conn = conn @ M[0]
+    assert torch.equal(conn > 0, torch.triu(conn > 0, diagonal=1)), "strictly upper triangular connectivity"
 
 
 def test_param_init_matches_reference_rng():

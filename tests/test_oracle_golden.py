@@ -98,6 +98,37 @@ def test_flow_gradients(oracle):
     torch.testing.assert_close(z.grad, T(g[k + "grad_z"]), rtol=1e-4, atol=1e-7)
 
 
+def test_maf_cases(oracle):
+    g = load_golden("maf")
+    for ci, (D, L, U, fwd, Mz, Mp, N, dt) in enumerate(g["meta"].tolist()):
+        k = "m%02d_" % ci
+        ms = [g[k + "ms%d" % i] for i in range(L + 1)]
+        # masks follow from the stored degree vectors exactly as in MAF._get_masks
+        m_prev = np.arange(1, D + 1) if fwd else np.arange(D, -1, -1)
+        Ms, k_prev = [], D
+        for m in ms[:-1]:
+            Ms.append((m_prev[:k_prev, None] <= m[None, :]).astype(np.float32))
+            k_prev, m_prev = len(m), m
+        Ms.append((m_prev[:k_prev, None] < ms[-1][None, :D]).astype(np.float32))
+        z, p = T(g[k + "z"]), T(g[k + "params"])
+        Msd = [M.astype(np.float64) for M in Ms] if dt else Ms
+        zf, ldf = oracle.maf(z, p, D, L, U, Msd, False)
+        zi, ldi = oracle.maf(z, p, D, L, U, Msd, True)
+        close(zf, g[k + "z_fwd"]); close(ldf, g[k + "ld_fwd"])
+        close(zi, g[k + "z_inv"]); close(ldi, g[k + "ld_inv"])
+    for ci, (D, L, U, N) in enumerate(g["flow_meta"].tolist()):
+        k = "n%02d_" % ci
+        ms = [g[k + "ms%d" % i] for i in range(L + 1)]
+        Ms, k_prev, m_prev = [], D, np.arange(1, D + 1)
+        for m in ms[:-1]:
+            Ms.append((m_prev[:k_prev, None] <= m[None, :]).astype(np.float32))
+            k_prev, m_prev = len(m), m
+        Ms.append((m_prev[:k_prev, None] < ms[-1][None, :D]).astype(np.float32))
+        stat = (T(g[k + "bn_mean"]), T(g[k + "bn_alpha"]))
+        lp = oracle.ar_flow_log_prob(T(g[k + "z_test"]), T(g[k + "params"]), D, L, U, Ms, stat)
+        torch.testing.assert_close(lp, T(g[k + "log_prob"]), rtol=1e-6, atol=1e-5)
+
+
 def test_cde_cases(oracle):
     g = load_golden("cde")
     for ci, row in enumerate(g["meta"].tolist()):

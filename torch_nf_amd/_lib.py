@@ -41,6 +41,10 @@ SIGNATURES = {
                                            _i64, _i64, _vp]),
     "tnf_bn_apply_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_bn_batch_backward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "tnf_maf_num_params": (_i64, [_i32, _i32, _i32]),
+    "tnf_maf": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _vp]),
+    "tnf_maf_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                        _i32, _i64, _i64, _vp]),
     "tnf_base_log_density_f64": (ctypes.c_int, [_i32, _vp, _vp, _i64, _i32, _vp]),
     "tnf_flow_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32, _i32]),
     "tnf_flow_fused_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),

@@ -227,3 +227,86 @@ class BatchNorm(Bijector):
 
     def inverse_and_log_det(self, z):
         return ops.bn_apply(z, self._last_mean, self._last_alpha, True)
+
+
+def _clamp_maf_layers(val):
+    if val < 1:
+        raise ValueError("MAF.num_layers must be positive.")
+    if val > 5:
+        print("Warning: MAF.num_layers set to maximum of 5 (received %d)." % val)
+        return 5
+    return val
+
+
+def _clamp_maf_units(val):
+    if val < 5:
+        print("Warning: num_units set to minimum of 15 (received %d)." % val)  # sic: the reference stores 5
+        return 5
+    if val > 1000:
+        print("Warning: num_units set to maximum of 1,000 (received %d)." % val)
+        return 1000
+    return val
+
+
+class MAF(Bijector):
+    """Masked autoregressive flow bijector (bijectors.py:597-806), the bijector of NormFlow's default
+    arch_type "AR".
+
+    Twin masked MLPs (f_mu, f_alpha), no biases, tanh on the hidden layers.  The degree vectors are
+    drawn at construction from the host numpy RNG exactly like the reference (np.random.randint per
+    hidden layer, bijectors.py:673), so np.random.seed reproduces the reference's masks; `ms` / `Ms`
+    are kept as attributes like in the reference.  inverse_and_log_det is one kernel pass,
+    forward_and_log_det runs the reference's D-1 sequential passes inside one kernel.
+    """
+
+    num_layers = _Checked("num_layers", int, _clamp_maf_layers)
+    num_units = _Checked("num_units", int, _clamp_maf_units)
+    fwd_fac = _Checked("fwd_fac", bool)
+
+    def __init__(self, D, num_layers, num_units, fwd_fac=True):
+        super().__init__(D)
+        self.name = "MAF"
+        self.num_layers = num_layers
+        self.num_units = num_units
+        self.fwd_fac = fwd_fac
+        self._get_masks()
+
+    def _get_masks(self):
+        """bijectors.py:663-696 (the odd arange(D, -1, -1) of fwd_fac=False included)."""
+        D, K = self.D, self.num_units
+        ms, Ms = [], []
+        k_prev = D
+        m_prev = np.arange(1, D + 1) if self.fwd_fac else np.arange(D, -1, -1)
+        for _ in range(self.num_layers):
+            m = np.random.randint(1, D, (K,))
+            Ms.append((m_prev[:k_prev, None] <= m[None, :]).astype(np.float32))
+            ms.append(m)
+            k_prev, m_prev = K, m
+        m = np.arange(1, D + 1) if self.fwd_fac else np.arange(D, -1, -1)
+        Ms.append((m_prev[:k_prev, None] < m[None, :D]).astype(np.float32))
+        ms.append(m)
+        self.set_masks(ms, Ms)
+        return None
+
+    def set_masks(self, ms, Ms=None):
+        """Install degree vectors (e.g. restored from a checkpoint); the masks follow from them."""
+        if Ms is None:
+            D = self.D
+            Ms, k_prev = [], D
+            m_prev = np.arange(1, D + 1) if self.fwd_fac else np.arange(D, -1, -1)
+            for m in ms[:-1]:
+                Ms.append((np.asarray(m_prev)[:k_prev, None] <= np.asarray(m)[None, :]).astype(np.float32))
+                k_prev, m_prev = len(m), m
+            Ms.append((np.asarray(m_prev)[:k_prev, None] < np.asarray(ms[-1])[None, :D]).astype(np.float32))
+        self.ms = [np.asarray(m) for m in ms]
+        self.Ms = [torch.tensor(M[None, :, :]).float() for M in Ms]
+        self._masks_flat = torch.cat([torch.tensor(M).float().reshape(-1) for M in Ms])
+
+    def forward_and_log_det(self, z, params):
+        return ops.maf(z, params, self._masks_flat, self.D, self.num_layers, self.num_units, False)
+
+    def inverse_and_log_det(self, z, params):
+        return ops.maf(z, params, self._masks_flat, self.D, self.num_layers, self.num_units, True)
+
+    def count_num_params(self):
+        return int(2 * (2 * self.D * self.num_units + (self.num_layers - 1) * (self.num_units ** 2)))

@@ -250,6 +250,42 @@ int tnf_bn_batch_backward_f32(const float* z_norm, const float* g_z_out, const f
     return launch_bn_batch_backward(z_norm, g_z_out, g_log_det, alpha, g_z, rows, D, workspace, as_stream(stream));
 }
 
+int64_t tnf_maf_num_params(int32_t D, int32_t L, int32_t U) {
+    if (D < 1 || L < 1 || U < 1) return fail(TNF_EINVAL, "tnf_maf_num_params: D=%d L=%d U=%d", D, L, U);
+    return 2 * (2 * (int64_t)D * U + (int64_t)(L - 1) * U * U);
+}
+
+int tnf_maf(int32_t dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
+            int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U, int32_t inverse, int64_t pstride,
+            void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_maf: dtype %d", dtype);
+    int rc = check_mnd("tnf_maf", M_z, M_p, N, D);
+    if (rc) return rc;
+    if (L < 1 || U < 1) return fail(TNF_EINVAL, "tnf_maf: num_layers=%d num_units=%d", L, U);
+    if (pstride < tnf_maf_num_params(D, L, U))
+        return fail(TNF_EINVAL, "tnf_maf: params row has %lld elements, layer needs %lld", (long long)pstride,
+                    (long long)tnf_maf_num_params(D, L, U));
+    if (!z || !params || !masks || !z_out || !log_det) return fail(TNF_EINVAL, "tnf_maf: NULL pointer");
+    if (N == 0) return TNF_OK;
+    return launch_maf(dtype, z, params, masks, z_out, log_det, M_z, M_p, N, D, L, U, inverse, pstride, as_stream(stream));
+}
+
+int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
+                     const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                     int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_maf_backward: dtype %d", dtype);
+    if (M < 1 || N < 0 || D < 1 || L < 1 || U < 1 || (M_p != 1 && M_p != M))
+        return fail(TNF_EINVAL, "tnf_maf_backward: M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", (long long)M,
+                    (long long)M_p, (long long)N, D, L, U);
+    const int64_t need = tnf_maf_num_params(D, L, U);
+    if (pstride < need || gpstride < need) return fail(TNF_EINVAL, "tnf_maf_backward: parameter rows shorter than %lld", (long long)need);
+    if (!z || !params || !masks || !g_z_out || !g_log_det || !g_z || !g_params)
+        return fail(TNF_EINVAL, "tnf_maf_backward: NULL pointer");
+    if (N == 0) return TNF_OK;
+    return launch_maf_backward(dtype, z, params, masks, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
+                               pstride, gpstride, as_stream(stream));
+}
+
 int tnf_base_log_density_f64(int32_t dtype, const void* omega, double* out, int64_t rows, int32_t D,
                              void* stream) {
     if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_base_log_density_f64: dtype %d", dtype);

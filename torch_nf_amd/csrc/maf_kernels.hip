@@ -1,0 +1,337 @@
+// MAF (masked autoregressive flow) bijector -- the reference's NormFlow default arch_type "AR"
+// (bijectors.py:597-806).  Twin masked MLPs (f_mu, f_alpha) without biases over ALL D inputs:
+//   inverse (density evaluation, ONE pass):  z' = (z - f_mu(z)) / exp(f_alpha(z)),  ld = sum f_alpha
+//   forward (sampling, D-1 sequential passes): z_{i+1} = u * exp(f_alpha(z_i)) + f_mu(z_i), z_0 = u
+// Shape- and dtype-generic like generic_kernels.hip: one workgroup = one parameter row m and a
+// tile of TS samples, activations ping-pong through LDS, masked weights stream from L2.
+// Packed parameters (bijectors.py:698-740): [W_mu0 | W_alpha0 | ... | W_mu_last | W_alpha_last],
+// W row-major [in][out]; `masks` holds one binary matrix per layer in the same order/shape
+// (D x U, (U x U) x (L-1), U x D), shared by both nets and by all parameter rows.
+#include "tnf_common.h"
+
+namespace tnf {
+
+template <typename T>
+__device__ __forceinline__ T maf_tanh(T x);
+template <>
+__device__ __forceinline__ float maf_tanh<float>(float x) { return tanhf(x); }
+template <>
+__device__ __forceinline__ double maf_tanh<double>(double x) { return tanh(x); }
+template <typename T>
+__device__ __forceinline__ T maf_exp(T x);
+template <>
+__device__ __forceinline__ float maf_exp<float>(float x) { return expf(x); }
+template <>
+__device__ __forceinline__ double maf_exp<double>(double x) { return exp(x); }
+
+// one evaluation of the twin masked nets on the tile: input zin [TS][W] -> mu, alpha in bm[cur], ba[cur]
+template <typename T>
+__device__ __forceinline__ int maf_net(const T* __restrict__ params, const T* __restrict__ masks, const T* zin,
+                                       T* bm0, T* bm1, T* ba0, T* ba1, int ts, int D, int L, int U, int W,
+                                       int tid) {
+    T* bm[2] = {bm0, bm1};
+    T* ba[2] = {ba0, ba1};
+    const T* p = params;
+    const T* mk = masks;
+    int cur = 0;
+    for (int l = 0; l <= L; ++l) {
+        const int din = (l == 0) ? D : U;
+        const int dout = (l == L) ? D : U;
+        const int64_t nw = (int64_t)din * dout;
+        const T* wm = p;
+        const T* wa = p + nw;
+        p += 2 * nw;
+        const T* xm = (l == 0) ? zin : bm[cur];
+        const T* xa = (l == 0) ? zin : ba[cur];
+        T* om = bm[cur ^ 1];
+        T* oa = ba[cur ^ 1];
+        for (int idx = tid; idx < ts * dout; idx += 256) {
+            const int i = idx / dout, o = idx - i * dout;
+            T am = 0, aa = 0;
+            for (int k = 0; k < din; ++k) {
+                const T mv = mk[(int64_t)k * dout + o];
+                am += xm[i * W + k] * (mv * wm[(int64_t)k * dout + o]);
+                aa += xa[i * W + k] * (mv * wa[(int64_t)k * dout + o]);
+            }
+            if (l < L) {
+                am = maf_tanh<T>(am);
+                aa = maf_tanh<T>(aa);
+            }
+            om[i * W + o] = am;
+            oa[i * W + o] = aa;
+        }
+        mk += nw;
+        __syncthreads();
+        cur ^= 1;
+    }
+    return cur;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+maf_kernel(const T* __restrict__ z, const T* __restrict__ params, const T* __restrict__ masks,
+           T* __restrict__ z_out, T* __restrict__ log_det, int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U,
+           int inverse, int64_t pstride, int TS, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int64_t m = grid_m();
+    if (m >= (Mz > Mp ? Mz : Mp)) return;
+    const int64_t n0 = (int64_t)blockIdx.x * TS;
+    const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
+    const int64_t plane = (int64_t)TS * W;
+    T* bm[2] = {smem, smem + plane};
+    T* ba[2] = {smem + 2 * plane, smem + 3 * plane};
+    T* zc = smem + 4 * plane;   // current iterate [TS][W]
+    const T* zt = z + ((Mz == 1 ? 0 : m) * N + n0) * D;
+    T* zo = z_out + (m * N + n0) * D;
+    const T* p = params + (Mp == 1 ? 0 : m) * pstride;
+
+    for (int idx = tid; idx < ts * D; idx += 256) {
+        const int i = idx / D, d = idx - i * D;
+        zc[i * W + d] = zt[(int64_t)i * D + d];
+    }
+    __syncthreads();
+    if (inverse) {
+        const int cur = maf_net<T>(p, masks, zc, bm[0], bm[1], ba[0], ba[1], ts, D, L, U, W, tid);
+        for (int idx = tid; idx < ts * D; idx += 256) {
+            const int i = idx / D, d = idx - i * D;
+            zo[(int64_t)i * D + d] = (zc[i * W + d] - bm[cur][i * W + d]) / maf_exp<T>(ba[cur][i * W + d]);
+        }
+        if (tid < ts) {
+            T acc = 0;
+            for (int d = 0; d < D; ++d) acc += ba[cur][tid * W + d];
+            log_det[m * N + n0 + tid] = acc;
+        }
+    } else {
+        int cur = 0;
+        for (int it = 0; it < D - 1; ++it) {  // bijectors.py:752-754
+            cur = maf_net<T>(p, masks, zc, bm[0], bm[1], ba[0], ba[1], ts, D, L, U, W, tid);
+            for (int idx = tid; idx < ts * D; idx += 256) {
+                const int i = idx / D, d = idx - i * D;
+                zc[i * W + d] = zt[(int64_t)i * D + d] * maf_exp<T>(ba[cur][i * W + d]) + bm[cur][i * W + d];
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < ts * D; idx += 256) {
+            const int i = idx / D, d = idx - i * D;
+            zo[(int64_t)i * D + d] = zc[i * W + d];
+        }
+        if (tid < ts) {
+            T acc = 0;
+            for (int d = 0; d < D; ++d) acc += ba[cur][tid * W + d];
+            log_det[m * N + n0 + tid] = acc;
+        }
+    }
+}
+
+static int maf_tile(int D, int U, int L, size_t esz, int planes, int64_t N, int* W_out, size_t* smem_out) {
+    int W = D > U ? D : U;
+    (void)L;
+    int64_t TS = (int64_t)(64 * 1024) / (int64_t)((size_t)planes * W * esz);
+    if (TS > 64) TS = 64;
+    if (TS > N) TS = N;
+    if (TS < 1) TS = 1;
+    *W_out = W;
+    *smem_out = (size_t)planes * TS * W * esz;
+    return (int)TS;
+}
+
+int launch_maf(int dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
+               int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st) {
+    const int64_t M = Mz > Mp ? Mz : Mp;
+    const size_t esz = dtype == TNF_F64 ? 8 : 4;
+    int W;
+    size_t smem;
+    const int TS = maf_tile(D, U, L, esz, 5, N, &W, &smem);
+    if (smem > 160 * 1024) return fail(TNF_EUNSUPPORTED, "maf: layer width %d needs %zu B of LDS", W, smem);
+    const int64_t tiles = (N + TS - 1) / TS;
+    if (tiles > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "maf: grid too large");
+    const dim3 grid = grid_xm(tiles, M);
+    if (dtype == TNF_F32) {
+        auto k = maf_kernel<float>;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const float*)z, (const float*)params, (const float*)masks,
+                           (float*)z_out, (float*)log_det, Mz, Mp, N, D, L, U, inverse, pstride, TS, W);
+    } else {
+        auto k = maf_kernel<double>;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const double*)z, (const double*)params,
+                           (const double*)masks, (double*)z_out, (double*)log_det, Mz, Mp, N, D, L, U, inverse,
+                           pstride, TS, W);
+    }
+    return check_launch("maf");
+}
+
+// ---------------------------------------------------------------------------
+// Backward of the inverse direction (what log_prob training differentiates):
+//   out = (z - mu) e^-alpha, ld = sum alpha
+//   dz = g e^-alpha + (nets' input gradient),  dmu = -g e^-alpha,  dalpha = -g out + g_ld
+// LDS: actx [TS][W] (= z), act[net][l = 1..L][TS][W], out[net][TS][W], delta[net][2][TS][W].
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const T* __restrict__ masks,
+                    const T* __restrict__ g_zout, const T* __restrict__ g_ld, T* __restrict__ g_z,
+                    T* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N, int D, int L, int U,
+                    int64_t pstride, int64_t gpstride, int TS, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int64_t m = grid_m();
+    if (m >= M) return;
+    const int64_t n0 = (int64_t)blockIdx.x * TS;
+    const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
+    const int64_t mp = Mp == 1 ? 0 : m;
+    const T* zt = z + (m * N + n0) * D;
+    const T* gzo = g_zout + (m * N + n0) * D;
+    T* gz = g_z + (m * N + n0) * D;
+    const T* p0 = params + mp * pstride;
+    T* gp0 = g_params + mp * gpstride;
+    const int64_t plane = (int64_t)TS * W;
+    T* actx = smem;
+    T* acts = smem + plane;                       // [2][L][TS][W]
+    T* outb = acts + 2 * (int64_t)L * plane;      // [2][TS][W]  mu, alpha
+    T* dlt = outb + 2 * plane;                    // [2][2][TS][W]
+    auto act = [&](int net, int l) -> T* { return l == 0 ? actx : acts + ((int64_t)net * L + (l - 1)) * plane; };
+
+    for (int idx = tid; idx < ts * D; idx += 256) {
+        const int i = idx / D, d = idx - i * D;
+        actx[i * W + d] = zt[(int64_t)i * D + d];
+    }
+    __syncthreads();
+    {   // forward recompute, keeping every activation
+        const T* p = p0;
+        const T* mk = masks;
+        for (int l = 0; l <= L; ++l) {
+            const int din = (l == 0) ? D : U, dout = (l == L) ? D : U;
+            const int64_t nw = (int64_t)din * dout;
+            const T* wm = p;
+            const T* wa = p + nw;
+            p += 2 * nw;
+            const T* xm = act(0, l);
+            const T* xa = act(1, l);
+            T* om = (l == L) ? outb : act(0, l + 1);
+            T* oa = (l == L) ? outb + plane : act(1, l + 1);
+            for (int idx = tid; idx < ts * dout; idx += 256) {
+                const int i = idx / dout, o = idx - i * dout;
+                T am = 0, aa = 0;
+                for (int k = 0; k < din; ++k) {
+                    const T mv = mk[(int64_t)k * dout + o];
+                    am += xm[i * W + k] * (mv * wm[(int64_t)k * dout + o]);
+                    aa += xa[i * W + k] * (mv * wa[(int64_t)k * dout + o]);
+                }
+                if (l < L) {
+                    am = maf_tanh<T>(am);
+                    aa = maf_tanh<T>(aa);
+                }
+                om[i * W + o] = am;
+                oa[i * W + o] = aa;
+            }
+            mk += nw;
+            __syncthreads();
+        }
+    }
+    int cur = 0;
+    for (int idx = tid; idx < ts * D; idx += 256) {
+        const int i = idx / D, d = idx - i * D;
+        const T mu = outb[i * W + d], al = outb[plane + i * W + d];
+        const T em = maf_exp<T>(-al);
+        const T g = gzo[(int64_t)i * D + d];
+        const T gl = g_ld[m * N + n0 + i];
+        const T dz = g * em;
+        gz[(int64_t)i * D + d] = dz;                              // direct path; the nets' share is added below
+        dlt[i * W + d] = -dz;                                     // d mu
+        dlt[2 * plane + i * W + d] = -g * ((actx[i * W + d] - mu) * em) + gl;  // d alpha
+    }
+    __syncthreads();
+    for (int l = L; l >= 0; --l) {
+        const int din = (l == 0) ? D : U, dout = (l == L) ? D : U;
+        int64_t off = 0, moff = 0;
+        for (int ll = 0; ll < l; ++ll) {
+            const int di = (ll == 0) ? D : U;
+            off += 2 * (int64_t)di * U;
+            moff += (int64_t)di * U;
+        }
+        const int64_t nw = (int64_t)din * dout;
+        const T* wm = p0 + off;
+        const T* wa = wm + nw;
+        const T* mk = masks + moff;
+        T* gwm = gp0 + off;
+        T* gwa = gwm + nw;
+        const T* dmc = dlt + (int64_t)cur * plane;
+        const T* dac = dlt + (2 + (int64_t)cur) * plane;
+        const T* xm = act(0, l);
+        const T* xa = act(1, l);
+        for (int64_t idx = tid; idx < nw; idx += 256) {
+            const int k = (int)(idx / dout), o = (int)(idx - (int64_t)k * dout);
+            const T mv = mk[idx];
+            if (mv != (T)0) {  // masked weights get exactly zero gradient, like autograd through Ms * W
+                T am = 0, aa = 0;
+                for (int i = 0; i < ts; ++i) {
+                    am += xm[i * W + k] * dmc[i * W + o];
+                    aa += xa[i * W + k] * dac[i * W + o];
+                }
+                atomicAdd(gwm + idx, mv * am);
+                atomicAdd(gwa + idx, mv * aa);
+            }
+        }
+        if (l > 0) {
+            T* dmn = dlt + (int64_t)(cur ^ 1) * plane;
+            T* dan = dlt + (2 + (int64_t)(cur ^ 1)) * plane;
+            for (int idx = tid; idx < ts * din; idx += 256) {
+                const int i = idx / din, k = idx - i * din;
+                T am = 0, aa = 0;
+                for (int o = 0; o < dout; ++o) {
+                    const T mv = mk[(int64_t)k * dout + o];
+                    am += mv * wm[(int64_t)k * dout + o] * dmc[i * W + o];
+                    aa += mv * wa[(int64_t)k * dout + o] * dac[i * W + o];
+                }
+                const T hm = xm[i * W + k], ha = xa[i * W + k];
+                dmn[i * W + k] = am * (1 - hm * hm);
+                dan[i * W + k] = aa * (1 - ha * ha);
+            }
+        } else {
+            for (int idx = tid; idx < ts * din; idx += 256) {
+                const int i = idx / din, k = idx - i * din;
+                T a = 0;
+                for (int o = 0; o < dout; ++o) {
+                    const T mv = mk[(int64_t)k * dout + o];
+                    a += mv * (wm[(int64_t)k * dout + o] * dmc[i * W + o] + wa[(int64_t)k * dout + o] * dac[i * W + o]);
+                }
+                gz[(int64_t)i * D + k] += a;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+int launch_maf_backward(int dtype, const void* z, const void* params, const void* masks, const void* g_zout,
+                        const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N, int D, int L,
+                        int U, int64_t pstride, int64_t gpstride, hipStream_t st) {
+    const size_t esz = dtype == TNF_F64 ? 8 : 4;
+    int W;
+    size_t smem;
+    const int TS = maf_tile(D, U, L, esz, 1 + 2 * L + 2 + 4, N, &W, &smem);
+    if (smem > 160 * 1024) return fail(TNF_EUNSUPPORTED, "maf_backward: layer width %d needs %zu B of LDS", W, smem);
+    const int64_t tiles = (N + TS - 1) / TS;
+    if (tiles > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "maf_backward: grid too large");
+    const dim3 grid = grid_xm(tiles, M);
+    if (dtype == TNF_F32) {
+        auto k = maf_backward_kernel<float>;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const float*)z, (const float*)params, (const float*)masks,
+                           (const float*)g_zout, (const float*)g_ld, (float*)g_z, (float*)g_params, M, Mp, N, D, L,
+                           U, pstride, gpstride, TS, W);
+    } else {
+        auto k = maf_backward_kernel<double>;
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const double*)z, (const double*)params,
+                           (const double*)masks, (const double*)g_zout, (const double*)g_ld, (double*)g_z,
+                           (double*)g_params, M, Mp, N, D, L, U, pstride, gpstride, TS, W);
+    }
+    return check_launch("maf_backward");
+}
+
+}  // namespace tnf

@@ -171,6 +171,11 @@ int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, 
 
 int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
                              int64_t rows, int D, void* ws, hipStream_t st);
+int launch_maf(int dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
+               int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st);
+int launch_maf_backward(int dtype, const void* z, const void* params, const void* masks, const void* g_zout,
+                        const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N, int D, int L,
+                        int U, int64_t pstride, int64_t gpstride, hipStream_t st);
 int launch_base_log_density(int dtype, const void* omega, double* out, int64_t rows, int D, hipStream_t st);
 
 }  // namespace tnf

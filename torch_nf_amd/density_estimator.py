@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .bijectors import Affine, BatchNorm, Bijector, RealNVP, _Checked
+from .bijectors import MAF, Affine, BatchNorm, Bijector, RealNVP, _Checked
 
 
 def _min_two(val):
@@ -124,10 +124,10 @@ class NormFlow(DensityEstimator):
                 self.bijectors.append(RealNVP(D, self.num_layers, self.num_units, transform_upper=False))
                 self.bijectors.append(BatchNorm(D))
                 self.bijectors.append(Affine(D))
-        elif self.arch_type == "AR":
-            raise NotImplementedError(
-                'NormFlow arch_type "AR" (MAF) is outside the MI355X hot path of this build; '
-                'use arch_type="coupling" or "affine".')
+        elif self.arch_type == "AR":  # density_estimator.py:271-274
+            self.bijectors.append(MAF(D, self.num_layers, self.num_units, fwd_fac=True))
+            self.bijectors.append(BatchNorm(D))
+            self.bijectors.append(Affine(D))
         else:
             self.bijectors.append(Affine(D))
 

@@ -99,3 +99,31 @@ def bn_batch_backward(z_norm, alpha, g_zn, g_ld):
                                         ac.data_ptr(), out.data_ptr(), rows, D, ws.data_ptr(), ws_bytes,
                                         _lib.stream_ptr()))
     return out if home == dev else out.to(home)
+
+
+def maf_backward(z, params, masks, g_z, g_ld, D, L, U):
+    dev = _lib.require_device()
+    home_z, home_p = z.device, params.device
+    code = _lib.F32 if z.dtype == torch.float32 else _lib.F64
+    zc = _dev(z.detach(), dev).contiguous()
+    pc = _dev(params.detach(), dev)
+    if pc.stride(1) != 1:
+        pc = pc.contiguous()
+    mk = _dev(masks.to(z.dtype), dev).contiguous()
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = max(Mz, Mp)
+    if Mz != M:
+        zc = zc.expand(M, N, D).contiguous()
+    g_zo = torch.zeros((M, N, D), dtype=z.dtype, device=dev) if g_z is None else _dev(g_z, dev).contiguous()
+    g_l = torch.zeros((M, N), dtype=z.dtype, device=dev) if g_ld is None else _dev(g_ld, dev).contiguous()
+    gz = torch.empty((M, N, D), dtype=z.dtype, device=dev)
+    gp = torch.zeros(tuple(params.shape), dtype=params.dtype, device=dev)
+    pstride = pc.stride(0) if Mp > 1 else max(pc.stride(0), pc.shape[1])
+    if N > 0:
+        check(lib.tnf_maf_backward(code, zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
+                                   gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, L, U, pstride, gp.shape[1],
+                                   _lib.stream_ptr()))
+    if Mz != M:
+        gz = gz.sum(0, keepdim=True)
+    return (gz if home_z == dev else gz.to(home_z)), (gp if home_p == dev else gp.to(home_p))

@@ -416,3 +416,60 @@ class _FlowLogProbFn(torch.autograd.Function):
 
 def flow_log_prob_train(z, params, bn_mean, bn_alpha, D, S, L, U):
     return _FlowLogProbFn.apply(z, params, bn_mean, bn_alpha, D, S, L, U)
+
+
+# ---------------------------------------------------------------------------
+# MAF (arch_type "AR")
+# ---------------------------------------------------------------------------
+def maf_raw(z, params, masks, D, L, U, inverse):
+    """tnf_maf.  masks: 1-D tensor (the layer masks concatenated).  Returns (z_out, log_det (M,N))."""
+    _check3(z)
+    dev = _lib.require_device()
+    home = z.device
+    code = _dtype_code(z)
+    if params.dtype != z.dtype:
+        raise TypeError("z (%s) and params (%s) must have the same dtype" % (z.dtype, params.dtype))
+    zc = _stage(z, dev)
+    pc, pstride = _rows(params, dev)
+    mk = _stage(masks.to(z.dtype), dev)
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = _bcast_M(Mz, Mp)
+    if zc.shape[2] != D:
+        raise ValueError("last dimension of z (%d) must equal D (%d)" % (zc.shape[2], D))
+    z_out = torch.empty((M, N, D), dtype=z.dtype, device=dev)
+    log_det = torch.empty((M, N), dtype=z.dtype, device=dev)
+    if N > 0:
+        check(lib.tnf_maf(code, zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), z_out.data_ptr(), log_det.data_ptr(),
+                          Mz, Mp, N, D, L, U, int(inverse), pstride, _lib.stream_ptr()))
+    if home != dev:
+        z_out, log_det = z_out.to(home), log_det.to(home)
+    return z_out, log_det
+
+
+class _MafFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, params, masks, D, L, U, inverse):
+        z_out, log_det = maf_raw(z, params, masks, D, L, U, inverse)
+        ctx.save_for_backward(z, params, masks)
+        ctx.cfg = (D, L, U, inverse)
+        return z_out, log_det
+
+    @staticmethod
+    def backward(ctx, g_z, g_ld):
+        from . import grad
+
+        z, params, masks = ctx.saved_tensors
+        D, L, U, inverse = ctx.cfg
+        if not inverse:
+            raise NotImplementedError(
+                "torch_nf_amd: autograd through MAF.forward_and_log_det (the D-1 pass sampling direction) is not "
+                "implemented; differentiate log_prob / inverse_and_log_det instead")
+        gz, gp = grad.maf_backward(z, params, masks, g_z, g_ld, D, L, U)
+        return gz, gp, None, None, None, None, None
+
+
+def maf(z, params, masks, D, L, U, inverse):
+    if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
+        return _MafFn.apply(z, params, masks, D, L, U, inverse)
+    return maf_raw(z, params, masks, D, L, U, inverse)
