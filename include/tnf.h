@@ -167,6 +167,29 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
                      int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                      int64_t g_params_row_stride, void* stream);
 
+/* ---- support layers (parameter-free bijectors appended by NormFlow(..., support_layer=)) ---- */
+/* ToInterval.forward_and_log_det / inverse_and_log_det (bijectors.py:509-557).  z, z_out (rows, D) and
+ * log_det (rows) of `dtype`; consts is a (7, D) float32 device array holding the bijector's constant rows
+ * tanh_flg, softplus_flg, tanh_m, tanh_c, softplus_m, softplus_c (bijectors.py:475-480) and
+ * log(tanh_m) evaluated in float32 like the reference does.  The inverse returns the forward
+ * log-det at the recovered point, like the reference.  eps = 1e-12 (:445, :556).
+ * tnf_to_interval_backward: g_z = g_z_out * d z_out/d z + g_log_det[row] * d log_det/d z for the
+ * direction `inverse`, recomputed from the layer's input z. */
+int tnf_to_interval(int32_t dtype, const void* z, const float* consts, void* z_out, void* log_det, int64_t rows,
+                    int32_t D, int32_t inverse, void* stream);
+int tnf_to_interval_backward(int32_t dtype, const void* z, const float* consts, const void* g_z_out,
+                             const void* g_log_det, void* g_z, int64_t rows, int32_t D, int32_t inverse,
+                             void* stream);
+/* ToSimplex.forward_and_log_det (bijectors.py:574-591): z (rows, D_in) -> z_out (rows, D_in + 1) on the
+ * simplex, log_det (rows) = log(1 - S/(S+1) + 1e-10) - D_attr*log(S+1) + sum z with S = sum exp z and
+ * D_attr the bijector's own D attribute (the reference uses self.D whatever the input width).  The
+ * reference defines no inverse.  tnf_to_simplex_backward: gradient w.r.t. z given g_z_out (rows, D_in+1)
+ * and g_log_det (rows). */
+int tnf_to_simplex(int32_t dtype, const void* z, void* z_out, void* log_det, int64_t rows, int32_t D_in,
+                   int32_t D_attr, void* stream);
+int tnf_to_simplex_backward(int32_t dtype, const void* z, const void* g_z_out, const void* g_log_det, void* g_z,
+                            int64_t rows, int32_t D_in, int32_t D_attr, void* stream);
+
 /* Base density of NormFlow.forward, float64 like the reference's numpy expression
  * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as
  * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)) in float64.  omega (rows, D) of `dtype` (TNF_F64 for

@@ -23,6 +23,9 @@ Reference citations (relative to the upstream repo root):
   * flow forward .............. torch_nf/density_estimator.py:364-388
   * flow inverse .............. torch_nf/density_estimator.py:390-406
   * log_prob .................. torch_nf/density_estimator.py:408-416
+  * MAF ....................... torch_nf/bijectors.py:597-806
+  * ToInterval / torch_atanh .. torch_nf/bijectors.py:429-557
+  * ToSimplex ................. torch_nf/bijectors.py:560-594
 """
 import math
 
@@ -49,6 +52,9 @@ __all__ = [
     "maf",
     "ar_flow_log_prob",
     "ar_flow_forward",
+    "interval_consts",
+    "to_interval",
+    "to_simplex",
 ]
 
 
@@ -341,3 +347,58 @@ def ar_flow_forward(omega, params, D, num_layers, num_units, Ms, bn_stat=None):
     z, ld = affine(z, params[:, n_maf:n_maf + 2 * D], D, False)
     log_q = log_q - ld
     return z, log_q, (mean, alpha)
+
+
+# --------------------------------------------------------------------------
+# Support layers
+# --------------------------------------------------------------------------
+def interval_consts(lb, ub):
+    """Per-feature constants of ToInterval.__init__ (bijectors.py:454-480): float32 (1,1,D) tensors
+    (tanh_flg, softplus_flg, tanh_m, tanh_c, softplus_m, softplus_c)."""
+    lb, ub = np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64)
+    D = lb.shape[0]
+    tf, sf = np.zeros(D), np.zeros(D)
+    tm, tc, sm, sc = np.ones(D), np.zeros(D), np.ones(D), np.zeros(D)
+    for i in range(D):
+        has_lb, has_ub = not np.isneginf(lb[i]), not np.isposinf(ub[i])
+        if has_lb and has_ub:
+            tf[i], tm[i], tc[i] = 1, (ub[i] - lb[i]) / 2.0, (ub[i] + lb[i]) / 2.0
+        elif has_lb:
+            sf[i], sm[i], sc[i] = 1, 1.0, lb[i]
+        elif has_ub:
+            sf[i], sm[i], sc[i] = 1, -1.0, ub[i]
+    return tuple(torch.tensor(a).float()[None, None, :] for a in (tf, sf, tm, tc, sm, sc))
+
+
+def _interval_tanh_ldj(z, tf, tm, eps):
+    tanh_z = torch.tanh(z)
+    return tanh_z, torch.sum(tf * (torch.log(tm) + torch.log(1.0 - (tanh_z ** 2) + eps)), axis=2)
+
+
+def to_interval(z, consts, inverse, eps=1e-12):
+    """ToInterval.forward_and_log_det (bijectors.py:509-527) / inverse_and_log_det (:529-553)."""
+    tf, sf, tm, tc, sm, sc = consts
+    if not inverse:
+        tanh_z, tanh_ldj = _interval_tanh_ldj(z, tf, tm, eps)
+        z = tf * (tm * tanh_z + tc) + (1 - tf) * z
+        out = sm * F.softplus(z) + sc
+        softplus_ldj = torch.sum(sf * F.logsigmoid(z), axis=2)
+        z = sf * out + (1 - sf) * z
+        return z, tanh_ldj + softplus_ldj
+    softplus_inv = torch.log(torch.exp(sf * (z - sc) / sm) - 1 + eps)
+    z = sf * softplus_inv + (1 - sf) * z
+    softplus_ldj = torch.sum(sf * F.logsigmoid(z), axis=2)
+    x = tf * (z - tc) / tm
+    tanh_inv = 0.5 * (torch.log(1 + x + eps) - torch.log(1 - x + eps))  # torch_atanh, :555-557
+    z = tf * tanh_inv + (1 - tf) * z
+    _, tanh_ldj = _interval_tanh_ldj(z, tf, tm, eps)
+    return z, tanh_ldj + softplus_ldj
+
+
+def to_simplex(z, D_attr):
+    """ToSimplex.forward_and_log_det (bijectors.py:574-591); D_attr is the bijector's D attribute."""
+    ex = torch.exp(z)
+    sum_ex = torch.sum(ex, dim=2)
+    den = sum_ex + 1.0
+    log_det = torch.log(1.0 - (sum_ex / den) + 1e-10) - D_attr * torch.log(den) + torch.sum(z, axis=2)
+    return torch.cat((ex / den[:, :, None], 1.0 / den[:, :, None]), axis=2), log_det

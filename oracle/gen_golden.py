@@ -361,11 +361,121 @@ def gen_maf():
     print("maf: %d bijector cases, %d AR flows" % (len(meta), len(fmeta)))
 
 
+def gen_support():
+    """ToInterval / ToSimplex alone and as NormFlow support layers (forward, log_prob, gradients)."""
+    out = {}
+    inf = np.inf
+    bounds = [
+        (4, [-inf] * 4, [inf] * 4, "f64", 1.0),
+        (4, [-0.5, -inf, -0.5, -inf], [0.5, 0.5, inf, inf], "f64", 2.0),       # the reference test's mix
+        (4, [-0.5, -inf, -0.5, -inf], [0.5, 0.5, inf, inf], "f32", 1.0),
+        (6, [-1.0, 0.0, -inf, 2.0, -3.0, -inf], [1.0, inf, 0.25, 7.5, inf, inf], "f32", 1.0),
+        (64, list(np.where(np.arange(64) % 3 == 0, -inf, -1.0 - np.arange(64) / 16.0)),
+         list(np.where(np.arange(64) % 4 == 1, inf, 1.0 + np.arange(64) / 8.0)), "f32", 1.0),
+    ]
+    meta = []
+    for ci, (D, lb, ub, dt, sig) in enumerate(bounds):
+        layer = rb.ToInterval(D, np.array(lb, dtype=np.float64), np.array(ub, dtype=np.float64))
+        consts = orc.interval_consts(lb, ub)
+        for a, b in zip(consts, (layer.tanh_flg, layer.softplus_flg, layer.tanh_m, layer.tanh_c, layer.softplus_m,
+                                 layer.softplus_c)):
+            assert same(a, b)
+        rng = np.random.RandomState(500 + ci)
+        M, N = (3, 17) if D < 64 else (2, 130)
+        z = torch.tensor(rng.normal(0.0, sig, (M, N, D))).to(tdtype(dt))
+        zf, ldf = layer(z)
+        zi, ldi = layer.inverse_and_log_det(zf)
+        ozf, oldf = orc.to_interval(z, consts, False)
+        ozi, oldi = orc.to_interval(zf, consts, True)
+        assert same(zf, ozf) and same(ldf, oldf) and same(zi, ozi) and same(ldi, oldi), ci
+        # gradients of a fixed linear functional of (out, log_det), both directions
+        wz, wl = torch.tensor(rng.normal(0, 1, (M, N, D))).to(z.dtype), torch.tensor(rng.normal(0, 1, (M, N))).to(z.dtype)
+        g = []
+        for inv, x in ((False, z), (True, zf.detach())):
+            xr = x.clone().requires_grad_()
+            o, l = layer.inverse_and_log_det(xr) if inv else layer(xr)
+            ((o * wz).sum() + (l * wl).sum()).backward()
+            g.append(xr.grad)
+        k = "i%02d_" % ci
+        out[k + "lb"], out[k + "ub"] = np.array(lb, dtype=np.float64), np.array(ub, dtype=np.float64)
+        out[k + "z"], out[k + "z_fwd"], out[k + "ld_fwd"] = npy(z), npy(zf), npy(ldf)
+        out[k + "z_inv"], out[k + "ld_inv"] = npy(zi), npy(ldi)
+        out[k + "wz"], out[k + "wl"], out[k + "g_fwd"], out[k + "g_inv"] = npy(wz), npy(wl), npy(g[0]), npy(g[1])
+        meta.append([D, M, N, 0 if dt == "f32" else 1])
+    out["interval_meta"] = np.array(meta, dtype=np.int64)
+
+    smeta = []
+    for ci, (Din, Dattr, M, N, dt) in enumerate([(3, 4, 20, 50, "f32"), (4, 4, 3, 9, "f64"), (64, 64, 2, 70, "f32"),
+                                                 (7, 7, 1, 33, "f32")]):
+        layer = rb.ToSimplex(Dattr)
+        rng = np.random.RandomState(600 + ci)
+        z = torch.tensor(rng.normal(0.0, 1.0, (M, N, Din))).to(tdtype(dt))
+        zr = z.clone().requires_grad_()
+        zf, ldf = layer(zr)
+        ozf, oldf = orc.to_simplex(z, Dattr)
+        assert same(zf.detach(), ozf) and same(ldf.detach(), oldf), ci
+        wz = torch.tensor(rng.normal(0, 1, (M, N, Din + 1))).to(z.dtype)
+        wl = torch.tensor(rng.normal(0, 1, (M, N))).to(z.dtype)
+        ((zf * wz).sum() + (ldf * wl).sum()).backward()
+        k = "s%02d_" % ci
+        out[k + "z"], out[k + "z_fwd"], out[k + "ld_fwd"] = npy(z), npy(zf), npy(ldf)
+        out[k + "wz"], out[k + "wl"], out[k + "g_fwd"] = npy(wz), npy(wl), npy(zr.grad)
+        smeta.append([Din, Dattr, M, N, 0 if dt == "f32" else 1])
+    out["simplex_meta"] = np.array(smeta, dtype=np.int64)
+
+    # NormFlow with a support layer: coupling + ToInterval (the LFI scripts' configuration,
+    # scripts/lfi_mat.py:37-40) and coupling + ToSimplex (tests/test_density_estimators.py:213)
+    fmeta = []
+    for ci, (D, S, L, U, N, kind) in enumerate([(6, 1, 2, 15, 40, "interval"), (32, 2, 2, 15, 64, "interval"),
+                                                (4, 2, 2, 20, 30, "simplex")]):
+        np.random.seed(700 + ci)
+        torch.manual_seed(700 + ci)
+        if kind == "interval":
+            lb = np.where(np.arange(D) % 3 == 0, -inf, -2.0 - np.arange(D) / 8.0)
+            ub = np.where(np.arange(D) % 3 == 1, inf, 2.5 + np.arange(D) / 4.0)
+            sup = rb.ToInterval(D, lb, ub)
+        else:
+            lb = ub = np.zeros(0)
+            sup = rb.ToSimplex(D)
+        nf = rde.NormFlow(D, False, "coupling", S, L, U, sup)
+        nf.params = torch.tensor(np.random.normal(0.0, 0.15, (1, nf.D_params))).float().requires_grad_()
+        params = nf.params.detach()
+        st = np.random.get_state()
+        omega = np.random.normal(0.0, 1.0, (1, N, D))
+        np.random.set_state(st)
+        z, log_q = nf(N)
+        bns = [b for b in nf.bijectors if b.name == "BatchNorm"]
+        k = "f%02d_" % ci
+        out[k + "lb"], out[k + "ub"] = lb, ub
+        out[k + "params"], out[k + "omega"] = npy(params), omega
+        out[k + "z_fwd"], out[k + "logq_fwd"] = npy(z), npy(log_q)
+        out[k + "bn_mean"] = np.stack([npy(b.get_last_mean()) for b in bns])
+        out[k + "bn_alpha"] = np.stack([npy(b.get_last_alpha()) for b in bns])
+        st = np.random.get_state()
+        omega2 = np.random.normal(0.0, 1.0, (1, N, D))
+        np.random.set_state(st)
+        with torch.no_grad():
+            z2, log_q2 = nf(N, freeze_bn=True)   # frozen statistics (new base draw)
+        out[k + "omega_frozen"], out[k + "z_frozen"], out[k + "logq_frozen"] = omega2, npy(z2), npy(log_q2)
+        if kind == "interval":
+            z_test = z.detach().clone()          # points inside the support
+            lp = nf.log_prob(z_test)
+            p = params.clone().requires_grad_()
+            nf.params = p
+            loss = -torch.mean(nf.log_prob(z_test))
+            loss.backward()
+            out[k + "log_prob"], out[k + "loss"], out[k + "grad_params"] = npy(lp), npy(loss), npy(p.grad)
+        fmeta.append([D, S, L, U, N, 0 if kind == "interval" else 1])
+    out["flow_meta"] = np.array(fmeta, dtype=np.int64)
+    np.savez(os.path.join(OUT, "support.npz"), **out)
+    print("support: %d interval, %d simplex, %d flows" % (len(meta), len(smeta), len(fmeta)))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = os.environ.get("GOLDEN_ONLY")  # e.g. GOLDEN_ONLY=maf regenerates one fixture file
     for name, fn in (("coupling", gen_coupling), ("affine_bn", gen_affine_bn), ("flow", gen_flow), ("cde", gen_cde),
-                     ("maf", gen_maf)):
+                     ("maf", gen_maf), ("support", gen_support)):
         if only is None or only == name:
             fn()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

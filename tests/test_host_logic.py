@@ -129,9 +129,41 @@ def test_normflow_validation_and_layout(capsys, oracle):
     nf = tnf.NormFlow(4, False, num_layers=2, num_units=20, device="cpu")
     assert nf.arch_type == "AR" and [type(b).__name__ for b in nf.bijectors] == ["MAF", "BatchNorm", "Affine"]
     assert nf.D_params == oracle.maf_num_params(4, 2, 20) + 8
-    # support layers are outside this build: loud, not silent
-    with raises(NotImplementedError):
-        tnf.NormFlow(4, False, "coupling", 1, 2, 20, tnf.Bijector(4))
+    # support layer: appended after the parameterised stack (density_estimator.py:278-282;
+    # reference tests/test_density_estimators.py:166-171, 213-224)
+    nf = tnf.NormFlow(4, True, "coupling", 2, 2, 20, tnf.ToSimplex(4))
+    assert len(nf.bijectors) == 11 and type(nf.bijectors[10]).__name__ == "ToSimplex"
+    assert issubclass(type(nf.support_layer), tnf.Bijector)
+    assert nf.D_params == oracle.flow_num_params(4, 2, 2, 20)
+    with raises(TypeError, match="Support layer not Bijector."):
+        tnf.NormFlow(4, True, "coupling", 2, 2, 20, "foo")
+
+
+def test_support_layer_validation(oracle):
+    """ToInterval / ToSimplex constructors (reference tests/test_bijectors.py:203-266, 349-353)."""
+    D = 4
+    lb, ub = -0.5 * np.array([1.0, np.inf, 1, np.inf]), 0.5 * np.array([1.0, 1.0, np.inf, np.inf])
+    iv = tnf.ToInterval(D, lb, ub)
+    assert iv.name == "ToInterval" and iv.D == D and iv.count_num_params() == 0 and iv._eps == 1e-12
+    ref = oracle.interval_consts(lb, ub)
+    for a, b in zip((iv.tanh_flg, iv.softplus_flg, iv.tanh_m, iv.tanh_c, iv.softplus_m, iv.softplus_c), ref):
+        assert a.dtype == torch.float32 and a.shape == (1, 1, D) and torch.equal(a, b)
+    assert iv._consts.shape == (7, D) and torch.equal(iv._consts[6], torch.log(iv._consts[2]))
+    with raises(ValueError, match="Lower and upper bounds must be same length."):
+        tnf.ToInterval(D, -np.ones((D,)), np.ones((D + 1,)))
+    ub_bad = np.ones((D,))
+    ub_bad[3] = -2
+    with raises(ValueError, match="Lower bound"):
+        tnf.ToInterval(D, -np.ones((D,)), ub_bad)
+    with raises(TypeError):
+        tnf.ToInterval(D, "[-1,-1,-1,-1]", np.ones((D,)))
+    with raises(TypeError):
+        tnf.ToInterval(D, -np.ones((D,)), "[1,1,1,1]")
+    assert isinstance(tnf.ToInterval(D, [-1, -1, -1, -1], [1, 1, 1, 1]).lb, np.ndarray)
+    sx = tnf.ToSimplex(D)
+    assert sx.name == "ToSimplex" and sx.D == D and sx.count_num_params() == 0
+    with raises(TypeError):  # no inverse in the reference: the base method wants params
+        sx.inverse_and_log_det(torch.zeros(1, 1, 3))
 
 
 def test_maf_validation_and_masks(capsys, oracle):

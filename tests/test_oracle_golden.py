@@ -129,6 +129,21 @@ def test_maf_cases(oracle):
         torch.testing.assert_close(lp, T(g[k + "log_prob"]), rtol=1e-6, atol=1e-5)
 
 
+def test_support_cases(oracle):
+    g = load_golden("support")
+    for ci, (D, M, N, dt) in enumerate(g["interval_meta"].tolist()):
+        k = "i%02d_" % ci
+        consts = oracle.interval_consts(g[k + "lb"], g[k + "ub"])
+        zf, ldf = oracle.to_interval(T(g[k + "z"]), consts, False)
+        zi, ldi = oracle.to_interval(T(g[k + "z_fwd"]), consts, True)
+        close(zf, g[k + "z_fwd"]); close(ldf, g[k + "ld_fwd"])
+        close(zi, g[k + "z_inv"]); close(ldi, g[k + "ld_inv"])
+    for ci, (Din, Dattr, M, N, dt) in enumerate(g["simplex_meta"].tolist()):
+        k = "s%02d_" % ci
+        zf, ldf = oracle.to_simplex(T(g[k + "z"]), Dattr)
+        close(zf, g[k + "z_fwd"]); close(ldf, g[k + "ld_fwd"])
+
+
 def test_cde_cases(oracle):
     g = load_golden("cde")
     for ci, row in enumerate(g["meta"].tolist()):

@@ -10,12 +10,12 @@ import sys
 
 from . import _lib  # noqa: F401  (fails loudly if libtnf_hip.so is missing)
 from . import bijectors, conditional_density_estimator, density_estimator, error_formatters
-from .bijectors import MAF, Affine, BatchNorm, Bijector, RealNVP
+from .bijectors import MAF, ToInterval, ToSimplex, Affine, BatchNorm, Bijector, RealNVP
 from .conditional_density_estimator import ConditionalDensityEstimator
 from .density_estimator import DensityEstimator, NormFlow
 
 __version__ = "0.1.0"
-__all__ = ["Bijector", "RealNVP", "MAF", "Affine", "BatchNorm", "DensityEstimator", "NormFlow",
+__all__ = ["Bijector", "RealNVP", "MAF", "ToInterval", "ToSimplex", "Affine", "BatchNorm", "DensityEstimator", "NormFlow",
            "ConditionalDensityEstimator", "install_as_torch_nf"]
 
 

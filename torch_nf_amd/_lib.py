@@ -41,6 +41,10 @@ SIGNATURES = {
                                            _i64, _i64, _vp]),
     "tnf_bn_apply_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_bn_batch_backward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "tnf_to_interval": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "tnf_to_interval_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "tnf_to_simplex": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "tnf_to_simplex_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_maf_num_params": (_i64, [_i32, _i32, _i32]),
     "tnf_maf": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _vp]),
     "tnf_maf_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,

@@ -310,3 +310,113 @@ class MAF(Bijector):
 
     def count_num_params(self):
         return int(2 * (2 * self.D * self.num_units + (self.num_layers - 1) * (self.num_units ** 2)))
+
+
+class ToInterval(Bijector):
+    """Maps each feature to an interval (bijectors.py:429-553): tanh where both bounds are finite,
+    +-softplus where one is, identity where neither.  Parameter-free; called as `layer(z)`.
+
+    :param D: Dimensionality of the bijection.
+    :type D: int
+    :param lb: Lower bound of interval.
+    :type lb: np.ndarray or list
+    :param ub: Upper bound of interval.
+    :type ub: np.ndarray or list
+    """
+
+    def __init__(self, D, lb, ub):
+        super().__init__(D)
+        self.name = "ToInterval"
+        self.lb = lb
+        self.ub = ub
+        self._eps = 1e-12
+
+        if self.lb.shape[0] != self.ub.shape[0]:
+            raise ValueError("Lower and upper bounds must be same length.")
+        for lb_i, ub_i in zip(self.lb, self.ub):
+            if lb_i > ub_i:
+                raise ValueError("Lower bound %.2E > upper bound %.2E." % (lb_i, ub_i))
+
+        # per-feature constants, float64 on the host then rounded to float32 like the reference (:454-480)
+        rows = np.zeros((6, self.D))
+        rows[2] = rows[4] = 1.0
+        for i in range(self.D):
+            lb_i, ub_i = self.lb[i], self.ub[i]
+            has_lb, has_ub = not np.isneginf(lb_i), not np.isposinf(ub_i)
+            if has_lb and has_ub:
+                rows[0, i], rows[2, i], rows[3, i] = 1, (ub_i - lb_i) / 2.0, (ub_i + lb_i) / 2.0
+            elif has_lb:
+                rows[1, i], rows[4, i], rows[5, i] = 1, 1.0, lb_i
+            elif has_ub:
+                rows[1, i], rows[4, i], rows[5, i] = 1, -1.0, ub_i
+        c = torch.tensor(rows).float()
+        (self.tanh_flg, self.softplus_flg, self.tanh_m, self.tanh_c, self.softplus_m,
+         self.softplus_c) = (c[i][None, None, :] for i in range(6))
+        # the kernels' constant block: the six rows + log(tanh_m) in float32 (torch.log(self.tanh_m), :515)
+        self._consts = torch.cat((c, torch.log(c[2:3])), 0).contiguous()
+        self._consts_dev = {}
+
+    def _check_bound(self, label, val):
+        if type(val) not in [list, np.ndarray]:
+            raise TypeError(format_type_err_msg(self, label, val, np.ndarray))
+        return np.array(val) if type(val) is list else val
+
+    @property
+    def lb(self):
+        return self._lb
+
+    @lb.setter
+    def lb(self, val):
+        self._lb = self._check_bound("lb", val)
+
+    @property
+    def ub(self):
+        return self._ub
+
+    @ub.setter
+    def ub(self, val):
+        self._ub = self._check_bound("ub", val)
+
+    def _device_consts(self):
+        from . import _lib
+
+        dev = _lib.require_device()
+        if dev not in self._consts_dev:
+            self._consts_dev[dev] = self._consts.to(dev)
+        return self._consts_dev[dev]
+
+    def __call__(self, z):
+        return self.forward_and_log_det(z)
+
+    def forward_and_log_det(self, z):
+        """bijectors.py:509-527 -> tnf_to_interval(inverse=0)."""
+        return ops.to_interval(z, self._device_consts(), False)
+
+    def inverse_and_log_det(self, z):
+        """bijectors.py:529-553 -> tnf_to_interval(inverse=1); like the reference, the log-det
+        returned is the forward one at the recovered point."""
+        return ops.to_interval(z, self._device_consts(), True)
+
+
+class ToSimplex(Bijector):
+    """Maps (M, N, D_in) to the simplex in D_in + 1 dimensions (bijectors.py:560-594).  Forward only:
+    the reference defines no inverse, so `inverse_and_log_det(z)` fails exactly as it does there
+    (the base class method wants `params`).
+
+    :param D: Dimensionality of the bijection.
+    :type D: int
+    """
+
+    def __init__(self, D):
+        super().__init__(D)
+        self.name = "ToSimplex"
+
+    def __call__(self, z):
+        return self.forward_and_log_det(z)
+
+    def forward_and_log_det(self, z):
+        """bijectors.py:574-591 -> tnf_to_simplex."""
+        return ops.to_simplex(z, self.D)
+
+    def count_num_params(self):
+        return 0

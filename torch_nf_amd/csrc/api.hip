@@ -286,6 +286,46 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
                                pstride, gpstride, as_stream(stream));
 }
 
+int tnf_to_interval(int32_t dtype, const void* z, const float* consts, void* z_out, void* log_det, int64_t rows,
+                    int32_t D, int32_t inverse, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_to_interval: dtype %d", dtype);
+    if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_to_interval: rows=%lld D=%d", (long long)rows, D);
+    if (rows == 0) return TNF_OK;
+    if (!z || !consts || !z_out || !log_det) return fail(TNF_EINVAL, "tnf_to_interval: NULL pointer");
+    return launch_to_interval(dtype, z, consts, z_out, log_det, rows, D, inverse, as_stream(stream));
+}
+
+int tnf_to_interval_backward(int32_t dtype, const void* z, const float* consts, const void* g_z_out,
+                             const void* g_log_det, void* g_z, int64_t rows, int32_t D, int32_t inverse,
+                             void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_to_interval_backward: dtype %d", dtype);
+    if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_to_interval_backward: rows=%lld D=%d", (long long)rows, D);
+    if (rows == 0) return TNF_OK;
+    if (!z || !consts || !g_z_out || !g_log_det || !g_z)
+        return fail(TNF_EINVAL, "tnf_to_interval_backward: NULL pointer");
+    return launch_to_interval_backward(dtype, z, consts, g_z_out, g_log_det, g_z, rows, D, inverse, as_stream(stream));
+}
+
+int tnf_to_simplex(int32_t dtype, const void* z, void* z_out, void* log_det, int64_t rows, int32_t D_in,
+                   int32_t D_attr, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_to_simplex: dtype %d", dtype);
+    if (rows < 0 || D_in < 1 || D_attr < 1)
+        return fail(TNF_EINVAL, "tnf_to_simplex: rows=%lld D_in=%d D_attr=%d", (long long)rows, D_in, D_attr);
+    if (rows == 0) return TNF_OK;
+    if (!z || !z_out || !log_det) return fail(TNF_EINVAL, "tnf_to_simplex: NULL pointer");
+    return launch_to_simplex(dtype, z, z_out, log_det, rows, D_in, D_attr, as_stream(stream));
+}
+
+int tnf_to_simplex_backward(int32_t dtype, const void* z, const void* g_z_out, const void* g_log_det, void* g_z,
+                            int64_t rows, int32_t D_in, int32_t D_attr, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_to_simplex_backward: dtype %d", dtype);
+    if (rows < 0 || D_in < 1 || D_attr < 1)
+        return fail(TNF_EINVAL, "tnf_to_simplex_backward: rows=%lld D_in=%d D_attr=%d", (long long)rows, D_in, D_attr);
+    if (rows == 0) return TNF_OK;
+    if (!z || !g_z_out || !g_log_det || !g_z) return fail(TNF_EINVAL, "tnf_to_simplex_backward: NULL pointer");
+    return launch_to_simplex_backward(dtype, z, g_z_out, g_log_det, g_z, rows, D_in, D_attr, as_stream(stream));
+}
+
 int tnf_base_log_density_f64(int32_t dtype, const void* omega, double* out, int64_t rows, int32_t D,
                              void* stream) {
     if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_base_log_density_f64: dtype %d", dtype);

@@ -171,6 +171,14 @@ int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, 
 
 int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
                              int64_t rows, int D, void* ws, hipStream_t st);
+int launch_to_interval(int dtype, const void* z, const float* consts, void* z_out, void* log_det, int64_t rows, int D,
+                       int inverse, hipStream_t st);
+int launch_to_interval_backward(int dtype, const void* z, const float* consts, const void* g_zout, const void* g_ld,
+                                void* g_z, int64_t rows, int D, int inverse, hipStream_t st);
+int launch_to_simplex(int dtype, const void* z, void* z_out, void* log_det, int64_t rows, int Din, int Dc,
+                      hipStream_t st);
+int launch_to_simplex_backward(int dtype, const void* z, const void* g_zout, const void* g_ld, void* g_z, int64_t rows,
+                               int Din, int Dc, hipStream_t st);
 int launch_maf(int dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
                int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st);
 int launch_maf_backward(int dtype, const void* z, const void* params, const void* masks, const void* g_zout,

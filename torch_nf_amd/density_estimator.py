@@ -11,8 +11,8 @@ Execution:
     (tnf_has_fast_path): ONE call of tnf_flow_log_prob_f32 / tnf_flow_forward_f32
     (whole flow in one kernel, or one kernel per coupling layer).
   * anything else: the reference's bijector loop, each bijector one HIP kernel.
-In scope are arch_type "coupling" and "affine"; "AR" (MAF) and the support layers
-are outside this hot path and raise NotImplementedError.
+arch_type "AR" (MAF) composes per bijector.  A support layer (ToInterval / ToSimplex) is one
+extra elementwise kernel after the stack in `forward` and before it in `log_prob`.
 """
 import numpy as np
 import torch
@@ -131,11 +131,12 @@ class NormFlow(DensityEstimator):
         else:
             self.bijectors.append(Affine(D))
 
+        self._n_core = len(self.bijectors)  # the parameterised stack; a support layer comes after it
         if support_layer is not None:
             if issubclass(type(support_layer), Bijector):
-                raise NotImplementedError(
-                    "support layers (ToInterval / ToSimplex) are outside the MI355X hot path of this build.")
-            raise TypeError("Support layer not Bijector.")
+                self.bijectors.append(support_layer)  # density_estimator.py:278-282
+            else:
+                raise TypeError("Support layer not Bijector.")
 
         self.count_num_params()
         if not self.conditioner:
@@ -236,7 +237,7 @@ class NormFlow(DensityEstimator):
             log_q = log_q - sld
         else:
             idx = 0
-            for bijector in self.bijectors:
+            for bijector in self.bijectors[:self._n_core]:
                 if bijector.name == "BatchNorm":
                     z, log_det = bijector(z, use_last=freeze_bn)
                 else:
@@ -244,6 +245,9 @@ class NormFlow(DensityEstimator):
                     z, log_det = bijector(z, p_dev[:, idx:idx + n])
                     idx += n
                 log_q = log_q - log_det
+        for bijector in self.bijectors[self._n_core:]:  # parameter-free support layer (:385-386)
+            z, log_det = bijector(z)
+            log_q = log_q - log_det
         if home != dev:
             z, log_q = z.to(home), log_q.to(home)
         return z, log_q
@@ -252,14 +256,20 @@ class NormFlow(DensityEstimator):
     def inverse_and_log_det(self, z, params):
         """Map z back to the base space, accumulating the forward log-dets
         (density_estimator.py:390-406).  Returns (z0, sum_log_det float32 (M,N))."""
-        if self._fused_ok(z, params):
+        if self._n_core == len(self.bijectors) and self._fused_ok(z, params):
             dev = _lib.require_device()
             mean, alpha = self._bn_stats(dev)
             _, z0, sld = ops.flow_log_prob_raw(z, params, mean, alpha, self.D, self.num_stages,
                                                self.num_layers, self.num_units, self.fusion,
                                                want_z0=True, want_sld=True, want_lp=False)
             return z0, sld
-        # generic composition: the reference's loop, one HIP kernel per bijector
+        return self._core_inverse(z, params, self.bijectors)
+
+    def _core_inverse(self, z, params, bijectors=None):
+        """The reference's loop, one HIP kernel per bijector (the whole stack, or only its
+        parameterised core when `bijectors` is None)."""
+        if bijectors is None:
+            bijectors = self.bijectors[:self._n_core]
         home = z.device
         dev = _lib.require_device()
         if home != dev:
@@ -269,7 +279,7 @@ class NormFlow(DensityEstimator):
         M = max(z.size(0), params.size(0))
         idx = self.D_params
         sum_log_det = torch.zeros((M, z.size(1)), device=dev)
-        for bijector in reversed(self.bijectors):
+        for bijector in reversed(bijectors):
             n = bijector.count_num_params()
             if n > 0:
                 z, log_det = bijector.inverse_and_log_det(z, params[:, idx - n:idx])
@@ -286,6 +296,14 @@ class NormFlow(DensityEstimator):
         """log q(z) (density_estimator.py:408-416)."""
         if not self.conditioner:
             params = self.params
+        if self._n_core < len(self.bijectors):
+            # support layer first (it is the last bijector of the stack), then the core's density:
+            # log q(z) = log q_core(s^-1(z)) - log|det ds| -- same sum as density_estimator.py:395-416
+            zc, ld_support = self.bijectors[-1].inverse_and_log_det(z)
+            return self._core_log_prob(zc, params) - ld_support
+        return self._core_log_prob(z, params)
+
+    def _core_log_prob(self, z, params):
         if self._fused_ok(z, params):
             dev = _lib.require_device()
             mean, alpha = self._bn_stats(dev)
@@ -300,6 +318,6 @@ class NormFlow(DensityEstimator):
             mean, alpha = self._bn_stats(_lib.require_device())
             return ops.flow_log_prob_train(z, params, mean, alpha, self.D, self.num_stages, self.num_layers,
                                            self.num_units)
-        z0, sum_log_det = self.inverse_and_log_det(z, params)
+        z0, sum_log_det = self._core_inverse(z, params)
         log_q = torch.sum(-(z0 ** 2), axis=2) / 2.0 - self.D * np.log(np.sqrt(2.0 * np.pi))
         return log_q - sum_log_det

@@ -473,3 +473,106 @@ def maf(z, params, masks, D, L, U, inverse):
     if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
         return _MafFn.apply(z, params, masks, D, L, U, inverse)
     return maf_raw(z, params, masks, D, L, U, inverse)
+
+
+# ---------------------------------------------------------------------------
+# Support layers (ToInterval / ToSimplex): parameter-free, elementwise + per-row log-det
+# ---------------------------------------------------------------------------
+def _grad_or_zeros(g, shape, dtype, dev):
+    if g is None:
+        return torch.zeros(shape, dtype=dtype, device=dev)
+    return _stage(g, dev)
+
+
+def to_interval_raw(z, consts, inverse):
+    """tnf_to_interval.  consts: (7, D) float32 rows (see include/tnf.h).  Returns (z_out, log_det (M,N))."""
+    _check3(z)
+    dev = _lib.require_device()
+    home = z.device
+    code = _dtype_code(z)
+    zc = _stage(z, dev)
+    cc = _stats(consts, dev)
+    M, N, D = zc.shape
+    if cc.shape != (7, D):
+        raise ValueError("last dimension of z (%d) must equal the bijector's D (%d)" % (D, cc.shape[1]))
+    z_out = torch.empty_like(zc)
+    log_det = torch.empty((M, N), dtype=z.dtype, device=dev)
+    check(lib.tnf_to_interval(code, zc.data_ptr(), cc.data_ptr(), z_out.data_ptr(), log_det.data_ptr(), M * N, D,
+                              int(inverse), _lib.stream_ptr()))
+    if home != dev:
+        z_out, log_det = z_out.to(home), log_det.to(home)
+    return z_out, log_det
+
+
+class _ToIntervalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, consts, inverse):
+        out = to_interval_raw(z, consts, inverse)
+        ctx.save_for_backward(z, consts)
+        ctx.inverse = inverse
+        return out
+
+    @staticmethod
+    def backward(ctx, g_z, g_ld):
+        z, consts = ctx.saved_tensors
+        dev = _lib.require_device()
+        zc = _stage(z.detach(), dev)
+        M, N, D = zc.shape
+        g_zo = _grad_or_zeros(g_z, (M, N, D), z.dtype, dev)
+        g_l = _grad_or_zeros(g_ld, (M, N), z.dtype, dev)
+        gz = torch.empty_like(zc)
+        check(lib.tnf_to_interval_backward(_dtype_code(z), zc.data_ptr(), _stats(consts, dev).data_ptr(),
+                                           g_zo.data_ptr(), g_l.data_ptr(), gz.data_ptr(), M * N, D,
+                                           int(ctx.inverse), _lib.stream_ptr()))
+        return (gz if z.device == dev else gz.to(z.device)), None, None
+
+
+def to_interval(z, consts, inverse):
+    if torch.is_grad_enabled() and z.requires_grad:
+        return _ToIntervalFn.apply(z, consts, inverse)
+    return to_interval_raw(z, consts, inverse)
+
+
+def to_simplex_raw(z, D_attr):
+    """tnf_to_simplex: (M, N, D_in) -> ((M, N, D_in + 1), log_det (M, N))."""
+    _check3(z)
+    dev = _lib.require_device()
+    home = z.device
+    code = _dtype_code(z)
+    zc = _stage(z, dev)
+    M, N, Din = zc.shape
+    z_out = torch.empty((M, N, Din + 1), dtype=z.dtype, device=dev)
+    log_det = torch.empty((M, N), dtype=z.dtype, device=dev)
+    check(lib.tnf_to_simplex(code, zc.data_ptr(), z_out.data_ptr(), log_det.data_ptr(), M * N, Din, D_attr,
+                             _lib.stream_ptr()))
+    if home != dev:
+        z_out, log_det = z_out.to(home), log_det.to(home)
+    return z_out, log_det
+
+
+class _ToSimplexFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, D_attr):
+        out = to_simplex_raw(z, D_attr)
+        ctx.save_for_backward(z)
+        ctx.D_attr = D_attr
+        return out
+
+    @staticmethod
+    def backward(ctx, g_z, g_ld):
+        (z,) = ctx.saved_tensors
+        dev = _lib.require_device()
+        zc = _stage(z.detach(), dev)
+        M, N, Din = zc.shape
+        g_zo = _grad_or_zeros(g_z, (M, N, Din + 1), z.dtype, dev)
+        g_l = _grad_or_zeros(g_ld, (M, N), z.dtype, dev)
+        gz = torch.empty_like(zc)
+        check(lib.tnf_to_simplex_backward(_dtype_code(z), zc.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
+                                          gz.data_ptr(), M * N, Din, ctx.D_attr, _lib.stream_ptr()))
+        return (gz if z.device == dev else gz.to(z.device)), None
+
+
+def to_simplex(z, D_attr):
+    if torch.is_grad_enabled() and z.requires_grad:
+        return _ToSimplexFn.apply(z, D_attr)
+    return to_simplex_raw(z, D_attr)
