@@ -66,7 +66,8 @@ const char* tnf_last_error(void);
 enum {
     TNF_OPT_FORCE_GENERIC = 1,
     TNF_OPT_FLOW_VARIANT = 2,  /* tuning: (tiles per wave, waves per workgroup) of the whole-flow kernel */
-    TNF_OPT_LAYER_VARIANT = 3  /* tuning: launch geometry of the per-layer kernel */
+    TNF_OPT_LAYER_VARIANT = 3, /* tuning: launch geometry of the per-layer kernel */
+    TNF_OPT_COND_VARIANT = 4   /* tuning: contexts per wave / waves per workgroup of the conditional-flow kernel */
 };
 int tnf_set_option(int32_t key, int32_t value);
 
@@ -166,6 +167,44 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
                      const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N,
                      int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                      int64_t g_params_row_stride, void* stream);
+
+/* ---- conditional flow, one sample per context (SNPE layout) ------------- */
+/* ConditionalDensityEstimator.log_prob(z[:, None, :], x) (conditional_density_estimator.py:101-104)
+ * with the last Linear of param_net fused into the flow: params[m] = W . h[m] + b is generated
+ * tile by tile on the matrix cores and consumed immediately, the (M, D_params) tensor never exists.
+ *   z (M, D) float32; h (M, ldh) float32, the first H columns = output of param_net's last activation;
+ *   W (D_params, ldw) / b (D_params) = weight / bias of param_net's last Linear (torch layout);
+ *   bn_mean / bn_alpha (2*S, D); log_prob (M); z0 (M, D) and sum_log_det (M) optional (NULL).
+ * Supported (tnf_cond_flow_supported): arch_type "coupling", D in {32, 64}, num_units <= 16,
+ * num_layers <= 5, H in {32, 64, 128} (pad h and W with zero columns for other widths).
+ * Rows of h and W must be 16-byte aligned (ldh, ldw multiples of 4). */
+int tnf_cond_flow_supported(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units, int32_t H);
+int64_t tnf_cond_flow_workspace_bytes(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units,
+                                      int32_t H);
+int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, const float* b,
+                               const float* bn_mean, const float* bn_alpha, float* log_prob, float* z0,
+                               float* sum_log_det, int64_t M, int32_t D, int32_t num_stages, int32_t num_layers,
+                               int32_t num_units, int32_t H, int64_t ldh, int64_t ldw, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
+/* ---- conditional flow, one sample per context (SNPE layout) ------------- */
+/* ConditionalDensityEstimator.log_prob(z[:, None, :], x) (conditional_density_estimator.py:101-104)
+ * with the last Linear of param_net fused into the flow: params[m] = W . h[m] + b is generated
+ * tile by tile on the matrix cores and consumed immediately, the (M, D_params) tensor never exists.
+ *   z (M, D) float32; h (M, ldh) float32, the first H columns = output of param_net's last activation;
+ *   W (D_params, ldw) / b (D_params) = weight / bias of param_net's last Linear (torch layout);
+ *   bn_mean / bn_alpha (2*S, D); log_prob (M); z0 (M, D) and sum_log_det (M) optional (NULL).
+ * Supported (tnf_cond_flow_supported): arch_type "coupling", D in {32, 64}, num_units <= 16,
+ * num_layers <= 5, H in {32, 64, 128} (pad h and W with zero columns for other widths).
+ * Rows of h and W must be 16-byte aligned (ldh, ldw multiples of 4). */
+int tnf_cond_flow_supported(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units, int32_t H);
+int64_t tnf_cond_flow_workspace_bytes(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units,
+                                      int32_t H);
+int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, const float* b,
+                               const float* bn_mean, const float* bn_alpha, float* log_prob, float* z0,
+                               float* sum_log_det, int64_t M, int32_t D, int32_t num_stages, int32_t num_layers,
+                               int32_t num_units, int32_t H, int64_t ldh, int64_t ldw, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 
 /* ---- support layers (parameter-free bijectors appended by NormFlow(..., support_layer=)) ---- */
 /* ToInterval.forward_and_log_det / inverse_and_log_det (bijectors.py:509-557).  z, z_out (rows, D) and

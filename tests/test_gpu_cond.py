@@ -1,0 +1,120 @@
+"""Fused conditioner + flow kernel (tnf_cond_flow_log_prob_f32): ConditionalDensityEstimator.log_prob with one
+sample per context (reference conditional_density_estimator.py:101-104 called as cde.log_prob(z[:, None, :], x))
+against the CPU oracle (param_net's last Linear in torch, then oracle.flow_log_prob) and against the
+materialised path of this package (hipBLASLt Linear + per-bijector kernels)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tnf():
+    import torch_nf_amd
+
+    assert torch.cuda.is_available()
+    return torch_nf_amd
+
+
+def _make(tnf, D, S, L, U, Dx, hidden, seed):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    cde = tnf.ConditionalDensityEstimator(nf, Dx, hidden)
+    g = torch.Generator().manual_seed(seed)
+    for b in nf._bn_layers():
+        b.set_last_stats(torch.randn(D, generator=g) * 0.1, torch.rand(D, generator=g) * 0.5 + 0.75)
+    with torch.no_grad():
+        for p in cde.param_net.parameters():
+            p.mul_(0.5)
+    return nf, cde
+
+
+def _oracle_lp(oracle, nf, cde, z, x):
+    net = cde.param_net.cpu().double()
+    params = net(x.cpu().double()).float()
+    stats = [(b.get_last_mean().cpu().float(), b.get_last_alpha().cpu().float()) for b in nf._bn_layers()]
+    lp = oracle.flow_log_prob(z.cpu(), params, nf.D, nf.num_stages, nf.num_layers, nf.num_units, stats)
+    cde.param_net.float().cuda()
+    return lp
+
+
+@pytest.mark.parametrize("D,S,L,U,Dx,hidden,M,variant", [
+    (64, 4, 2, 15, 32, [64, 64], 1000, 0),
+    (64, 4, 2, 15, 32, [64, 64], 257, 3),
+    (64, 1, 1, 16, 8, [32], 77, 2),
+    (32, 2, 3, 15, 5, [50], 300, 1),      # hidden width padded 50 -> 64
+    (32, 2, 2, 15, 5, [100, 100], 33, 3),  # padded 100 -> 128
+    (64, 2, 2, 15, 5, [128], 530, 0),
+    (32, 1, 2, 15, 6, [], 100, 0),         # no hidden layer: h = x, width padded 6 -> 32
+])
+def test_cond_flow_log_prob(tnf, oracle, D, S, L, U, Dx, hidden, M, variant):
+    from torch_nf_amd import _lib
+
+    nf, cde = _make(tnf, D, S, L, U, Dx, hidden, 11 + M)
+    x = torch.randn(M, Dx, device="cuda")
+    z = torch.randn(M, 1, D, device="cuda")
+    _lib.lib.tnf_set_option(_lib.OPT_COND_VARIANT, variant)
+    try:
+        with torch.no_grad():
+            assert cde._fused_conditioner_ok(z, x)
+            lp_f = cde.log_prob(z, x)
+            cde.fuse_conditioner = False
+            lp_m = cde.log_prob(z, x)
+    finally:
+        _lib.lib.tnf_set_option(_lib.OPT_COND_VARIANT, 0)
+    assert lp_f.shape == (M, 1) and lp_f.dtype == torch.float32
+    lp_o = _oracle_lp(oracle, nf, cde, z, x)
+    # north_star tolerance: log_prob rtol <= 1e-5 against the reference's CPU path
+    torch.testing.assert_close(lp_f.cpu(), lp_o, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lp_f, lp_m, rtol=1e-5, atol=1e-5)
+
+
+def test_cond_flow_outputs_and_selection(tnf, oracle):
+    from torch_nf_amd import ops
+
+    nf, cde = _make(tnf, 32, 2, 2, 15, 4, [64], 5)
+    M = 200
+    x = torch.randn(M, 4, device="cuda")
+    z = torch.randn(M, 1, 32, device="cuda")
+    with torch.no_grad():
+        h = cde.param_net[:-1](x)
+        last = cde.param_net[-1]
+        mean, alpha = nf._bn_stats(torch.device("cuda", torch.cuda.current_device()))
+        lp, z0, sld = ops.cond_flow_log_prob_raw(z[:, 0, :], h, last.weight, last.bias, mean, alpha, 32, 2, 2, 15,
+                                                 want_z0=True, want_sld=True)
+        z0_m, sld_m = nf.inverse_and_log_det(z, cde.param_net(x))
+    torch.testing.assert_close(z0, z0_m[:, 0, :], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(sld, sld_m[:, 0], rtol=1e-5, atol=1e-5)
+    ref = -0.5 * (z0 ** 2).sum(1) - 32 * np.log(np.sqrt(2 * np.pi)) - sld
+    torch.testing.assert_close(lp, ref, rtol=1e-5, atol=1e-5)
+    # selection: more than one sample per context, autograd, float64 or few contexts -> materialised path
+    assert not cde._fused_conditioner_ok(torch.randn(M, 2, 32, device="cuda"), x)
+    assert not cde._fused_conditioner_ok(z[:8], x[:8])
+    assert not cde._fused_conditioner_ok(z, x)  # grad mode with trainable param_net
+    with torch.no_grad():
+        assert cde._fused_conditioner_ok(z, x)
+        assert not cde._fused_conditioner_ok(z.double(), x)
+        # CPU inputs are staged and the result comes back on the CPU
+        lp_cpu = cde.log_prob(z.cpu(), x.cpu())
+    assert lp_cpu.device.type == "cpu"
+    torch.testing.assert_close(lp_cpu[:, 0], lp.cpu(), rtol=1e-6, atol=1e-6)
+
+
+def test_cond_flow_weight_scaling(tnf, oracle):
+    """Operand scaling: tiny and large last-layer weights keep fp32-level accuracy (the f16 halves are
+    scaled by a power of two chosen from max|W|, |b|)."""
+    for scale in (1e-4, 4.0):
+        nf, cde = _make(tnf, 32, 1, 2, 15, 4, [32], 3)
+        with torch.no_grad():
+            last = cde.param_net[-1]
+            last.weight.mul_(scale)
+            last.bias.mul_(min(scale, 1.0))
+            x = torch.randn(64, 4, device="cuda") * (0.05 if scale > 1 else 1.0)
+            z = torch.randn(64, 1, 32, device="cuda")
+            lp_f = cde.log_prob(z, x)
+        lp_o = _oracle_lp(oracle, nf, cde, z, x)
+        ok = torch.isfinite(lp_o[:, 0]) & (lp_o[:, 0].abs() < 1e4)  # large weights: some contexts blow up
+        assert ok.sum() > 32
+        torch.testing.assert_close(lp_f.cpu()[ok], lp_o[ok], rtol=2e-5, atol=2e-5)

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtnf_hip.so")
 F32, F64 = 0, 1
 LD_STORE, LD_ADD, LD_SUB = 0, 1, -1
 FUSE_AUTO, FUSE_LAYER, FUSE_FLOW = 0, 1, 2
-OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT = 1, 2, 3
+OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT, OPT_COND_VARIANT = 1, 2, 3, 4
 EUNSUPPORTED = -2
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
@@ -41,6 +41,10 @@ SIGNATURES = {
                                            _i64, _i64, _vp]),
     "tnf_bn_apply_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_bn_batch_backward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "tnf_cond_flow_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "tnf_cond_flow_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "tnf_cond_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
+                                                   _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
     "tnf_to_interval": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_to_interval_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_to_simplex": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -11,6 +11,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import _lib, ops
 from . import density_estimator as de
 from .bijectors import _Checked
 
@@ -53,6 +54,10 @@ class ConditionalDensityEstimator(torch.nn.Module):
                 layers.append(("dropout%d" % i, torch.nn.Dropout()))
         layers.append(("linear%d" % len(widths), torch.nn.Linear(widths[-1], self.D_params)))
         self.param_net = torch.nn.Sequential(OrderedDict(layers))
+        # extension (not in the reference): fuse param_net's last Linear into the flow kernel for
+        # one-sample-per-context calls with at least this many contexts
+        self.fuse_conditioner = True
+        self.fuse_min_contexts = 16
         if density_estimator.device.type != "cpu":
             self.param_net.to(density_estimator.device)
 
@@ -94,7 +99,37 @@ class ConditionalDensityEstimator(torch.nn.Module):
         params = self._params_for(x)
         return self.density_estimator(N=N, params=params, freeze_bn=freeze_bn)
 
+    def _fused_conditioner_ok(self, z, x):
+        """One sample per context (the SNPE layout z[:, None, :]) on a coupling flow: the last Linear
+        of param_net runs inside the flow kernel (tnf_cond_flow_log_prob_f32) and the (M, D_params)
+        parameter tensor is never materialised."""
+        nf = self.density_estimator
+        last = self.param_net[-1]
+        if not (self.fuse_conditioner and z.dim() == 3 and z.size(1) == 1 and x.dim() == 2
+                and z.size(0) == x.size(0) and z.size(0) >= self.fuse_min_contexts):
+            return False
+        if nf.arch_type != "coupling" or nf.support_layer is not None or z.size(2) != nf.D:
+            return False
+        if z.dtype != torch.float32 or x.dtype != torch.float32 or last.weight.dtype != torch.float32:
+            return False
+        if torch.is_grad_enabled() and (z.requires_grad or x.requires_grad
+                                        or any(p.requires_grad for p in self.param_net.parameters())):
+            return False  # training goes through the materialised path (autograd kernels)
+        return ops.cond_flow_supported(nf.D, nf.num_stages, nf.num_layers, nf.num_units, last.in_features)
+
     def log_prob(self, z, x):
         """conditional_density_estimator.py:101-104."""
+        if self._fused_conditioner_ok(z, x):
+            nf = self.density_estimator
+            last = self.param_net[-1]
+            weight = last.weight
+            home = z.device
+            xd = x if x.device == weight.device else x.to(weight.device)
+            h = self.param_net[:-1](xd) if len(self.param_net) > 1 else xd
+            mean, alpha = nf._bn_stats(_lib.require_device())
+            lp, _, _ = ops.cond_flow_log_prob_raw(z[:, 0, :], h, weight, last.bias, mean, alpha, nf.D,
+                                                  nf.num_stages, nf.num_layers, nf.num_units)
+            lp = lp[:, None]
+            return lp if lp.device == home else lp.to(home)
         params = self._params_for(x)
         return self.density_estimator.log_prob(z, params)

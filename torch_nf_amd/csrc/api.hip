@@ -81,6 +81,10 @@ int tnf_set_option(int32_t key, int32_t value) {
         g_layer_variant = value;
         return TNF_OK;
     }
+    if (key == TNF_OPT_COND_VARIANT) {
+        g_cond_variant = value;
+        return TNF_OK;
+    }
     return fail(TNF_EINVAL, "tnf_set_option: unknown key %d", key);
 }
 
@@ -284,6 +288,39 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
     if (N == 0) return TNF_OK;
     return launch_maf_backward(dtype, z, params, masks, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
                                pstride, gpstride, as_stream(stream));
+}
+
+int tnf_cond_flow_supported(int32_t D, int32_t S, int32_t L, int32_t U, int32_t H) {
+    return cond_flow_supported(D, S, L, U, H) ? 1 : 0;
+}
+
+int64_t tnf_cond_flow_workspace_bytes(int32_t D, int32_t S, int32_t L, int32_t U, int32_t H) {
+    if (!cond_flow_supported(D, S, L, U, H))
+        return fail(TNF_EUNSUPPORTED, "tnf_cond_flow_workspace_bytes: no kernel for D=%d S=%d L=%d U=%d H=%d", D, S, L, U, H);
+    return cond_flow_workspace(D, S, L, U, H);
+}
+
+int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, const float* b,
+                               const float* bn_mean, const float* bn_alpha, float* log_prob, float* z0,
+                               float* sum_log_det, int64_t M, int32_t D, int32_t S, int32_t L, int32_t U, int32_t H,
+                               int64_t ldh, int64_t ldw, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M < 0) return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_f32: M=%lld", (long long)M);
+    if (!cond_flow_supported(D, S, L, U, H))
+        return fail(TNF_EUNSUPPORTED, "tnf_cond_flow_log_prob_f32: no kernel for D=%d S=%d L=%d U=%d H=%d", D, S, L, U, H);
+    if (ldh < H || ldw < H || (ldh & 3) || (ldw & 3))
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_f32: ldh=%lld ldw=%lld must be multiples of 4 and >= H=%d",
+                    (long long)ldh, (long long)ldw, H);
+    if (M == 0) return TNF_OK;
+    if (!z || !h || !W || !b || !bn_mean || !bn_alpha || !log_prob || !workspace)
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_f32: NULL pointer");
+    if (((uintptr_t)h & 15) || ((uintptr_t)W & 15) || ((uintptr_t)z & 15) || ((uintptr_t)workspace & 255))
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_f32: z, h, W must be 16-byte and the workspace 256-byte aligned");
+    const int64_t need = cond_flow_workspace(D, S, L, U, H);
+    if (workspace_bytes < need)
+        return fail(TNF_EWORKSPACE, "tnf_cond_flow_log_prob_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)need);
+    return launch_cond_flow_log_prob(z, h, W, b, bn_mean, bn_alpha, log_prob, z0, sum_log_det, M, D, S, L, U, H, ldh,
+                                     ldw, workspace, as_stream(stream));
 }
 
 int tnf_to_interval(int32_t dtype, const void* z, const float* consts, void* z_out, void* log_det, int64_t rows,

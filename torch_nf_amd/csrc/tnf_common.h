@@ -66,6 +66,7 @@ __host__ __device__ inline FlowLayout flow_layout(int D, int S, int L, int U) {
 extern int g_force_generic;
 extern int g_flow_variant;   // flow_fused.hip
 extern int g_layer_variant;  // coupling_mfma.hip
+extern int g_cond_variant;   // cond_flow.hip
 
 // ---- kernels implemented in the .hip files ----------------------------------
 int launch_coupling_generic(int dtype, const void* z, const void* params, void* z_out,
@@ -171,6 +172,11 @@ int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, 
 
 int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
                              int64_t rows, int D, void* ws, hipStream_t st);
+bool cond_flow_supported(int D, int S, int L, int U, int H);
+int64_t cond_flow_workspace(int D, int S, int L, int U, int H);
+int launch_cond_flow_log_prob(const float* z, const float* h, const float* W, const float* b, const float* bn_mean,
+                              const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, int64_t M, int D,
+                              int S, int L, int U, int H, int64_t ldh, int64_t ldw, void* ws, hipStream_t st);
 int launch_to_interval(int dtype, const void* z, const float* consts, void* z_out, void* log_det, int64_t rows, int D,
                        int inverse, hipStream_t st);
 int launch_to_interval_backward(int dtype, const void* z, const float* consts, const void* g_zout, const void* g_ld,

@@ -576,3 +576,55 @@ def to_simplex(z, D_attr):
     if torch.is_grad_enabled() and z.requires_grad:
         return _ToSimplexFn.apply(z, D_attr)
     return to_simplex_raw(z, D_attr)
+
+
+# ---------------------------------------------------------------------------
+# Conditional flow with one sample per context: param_net's last Linear fused into the flow
+# ---------------------------------------------------------------------------
+def _cond_width(H):
+    for w in (32, 64, 128):
+        if H <= w:
+            return w
+    return 0
+
+
+def cond_flow_supported(D, S, L, U, H):
+    Hp = _cond_width(H)
+    return bool(Hp) and bool(lib.tnf_cond_flow_supported(D, S, L, U, Hp))
+
+
+def _pad_cols(t, width):
+    t = t.detach().float()
+    if t.shape[1] != width:
+        t = torch.nn.functional.pad(t, (0, width - t.shape[1]))
+    return t.contiguous()
+
+
+def cond_flow_log_prob_raw(z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U, want_z0=False, want_sld=False):
+    """tnf_cond_flow_log_prob_f32: z (M, D), h (M, H) = input of param_net's last Linear, weight
+    (D_params, H) / bias (D_params) of that Linear.  Returns (log_prob (M), z0 | None, sum_log_det | None)."""
+    dev = _lib.require_device()
+    M, H = h.shape
+    Hp = _cond_width(H)
+    if not Hp:
+        raise ValueError("conditioner width %d not supported by the fused kernel (max 128)" % H)
+    zc = _stage(z.detach().float(), dev)
+    if zc.shape != (M, D):
+        raise ValueError("z must be (M, D) = (%d, %d), got %s" % (M, D, tuple(zc.shape)))
+    hc = _pad_cols(_stage(h, dev), Hp)
+    wc = _pad_cols(_stage(weight, dev), Hp)
+    bc = _stage(bias.detach().float(), dev)
+    mean = _stats(bn_mean, dev)
+    alpha = _stats(bn_alpha, dev)
+    lp = torch.empty((M,), dtype=torch.float32, device=dev)
+    z0 = torch.empty((M, D), dtype=torch.float32, device=dev) if want_z0 else None
+    sld = torch.empty((M,), dtype=torch.float32, device=dev) if want_sld else None
+    nbytes = check(lib.tnf_cond_flow_workspace_bytes(D, S, L, U, Hp))
+    ws = _workspace(nbytes, dev)
+    if M > 0:
+        check(lib.tnf_cond_flow_log_prob_f32(zc.data_ptr(), hc.data_ptr(), wc.data_ptr(), bc.data_ptr(),
+                                             mean.data_ptr(), alpha.data_ptr(), lp.data_ptr(),
+                                             z0.data_ptr() if want_z0 else None,
+                                             sld.data_ptr() if want_sld else None, M, D, S, L, U, Hp,
+                                             hc.stride(0), wc.stride(0), ws.data_ptr(), nbytes, _lib.stream_ptr()))
+    return lp, z0, sld
