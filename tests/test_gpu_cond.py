@@ -89,10 +89,10 @@ def test_cond_flow_outputs_and_selection(tnf, oracle):
     torch.testing.assert_close(sld, sld_m[:, 0], rtol=1e-5, atol=1e-5)
     ref = -0.5 * (z0 ** 2).sum(1) - 32 * np.log(np.sqrt(2 * np.pi)) - sld
     torch.testing.assert_close(lp, ref, rtol=1e-5, atol=1e-5)
-    # selection: more than one sample per context, autograd, float64 or few contexts -> materialised path
+    # selection: more than one sample per context, float64 or few contexts -> materialised path
     assert not cde._fused_conditioner_ok(torch.randn(M, 2, 32, device="cuda"), x)
     assert not cde._fused_conditioner_ok(z[:8], x[:8])
-    assert not cde._fused_conditioner_ok(z, x)  # grad mode with trainable param_net
+    assert cde._fused_conditioner_ok(z, x)  # grad mode: the fused training pair
     with torch.no_grad():
         assert cde._fused_conditioner_ok(z, x)
         assert not cde._fused_conditioner_ok(z.double(), x)
@@ -118,3 +118,72 @@ def test_cond_flow_weight_scaling(tnf, oracle):
         ok = torch.isfinite(lp_o[:, 0]) & (lp_o[:, 0].abs() < 1e4)  # large weights: some contexts blow up
         assert ok.sum() > 32
         torch.testing.assert_close(lp_f.cpu()[ok], lp_o[ok], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("D,S,L,U,Dx,hidden,M,variant,weighted", [
+    (32, 1, 1, 15, 4, [32], 64, 1, False),
+    (32, 2, 2, 15, 4, [32], 100, 0, True),
+    (64, 4, 2, 15, 32, [64, 64], 300, 3, True),
+    (32, 2, 3, 15, 5, [50], 130, 3, False),
+    (64, 2, 2, 16, 5, [128], 77, 1, True),
+])
+def test_cond_flow_training_gradients(tnf, oracle, D, S, L, U, Dx, hidden, M, variant, weighted):
+    """-(w * log_prob).mean() through the fused training pair (tnf_cond_flow_log_prob_fwd/bwd_f32): gradients of
+    every param_net parameter and of z against (a) this package's materialised autograd path and (b) torch
+    autograd through the CPU oracle (= the reference's own training path, params materialised)."""
+    from torch_nf_amd import _lib
+
+    nf, cde = _make(tnf, D, S, L, U, Dx, hidden, 21 + M)
+    x = torch.randn(M, Dx, device="cuda")
+    z = torch.randn(M, 1, D, device="cuda", requires_grad=True)
+    w = (torch.rand(M, 1, device="cuda") + 0.1) if weighted else torch.ones(M, 1, device="cuda")
+    _lib.lib.tnf_set_option(_lib.OPT_COND_VARIANT, variant)
+    res = []
+    try:
+        for fuse in (True, False):
+            cde.fuse_conditioner = fuse
+            cde.zero_grad()
+            z.grad = None
+            assert cde._fused_conditioner_ok(z, x) == fuse
+            loss = -(cde.log_prob(z, x) * w).mean()
+            loss.backward()
+            res.append((loss.detach().cpu(), [p.grad.detach().cpu().clone() for p in cde.param_net.parameters()],
+                        z.grad.detach().cpu().clone()))
+    finally:
+        _lib.lib.tnf_set_option(_lib.OPT_COND_VARIANT, 0)
+    # (b) the oracle: double-precision param_net, float32 flow like the reference
+    net = cde.param_net.cpu()
+    for p in net.parameters():
+        p.grad = None
+    zc = z.detach().cpu().clone().requires_grad_()
+    stats = [(b.get_last_mean().cpu().float(), b.get_last_alpha().cpu().float()) for b in nf._bn_layers()]
+    lp = oracle.flow_log_prob(zc, net(x.cpu()), nf.D, nf.num_stages, nf.num_layers, nf.num_units, stats)
+    loss_o = -(lp * w.cpu()).mean()
+    loss_o.backward()
+    ref = (loss_o.detach(), [p.grad.clone() for p in net.parameters()], zc.grad.clone())
+    cde.param_net.cuda()
+
+    def close(a, b, tol):
+        scale = float(b.abs().max().clamp_min(1e-30))
+        assert float((a - b).abs().max()) <= tol * scale, (float((a - b).abs().max()), scale)
+
+    for other, tol in ((res[1], 2e-5), (ref, 5e-5)):
+        torch.testing.assert_close(res[0][0], other[0], rtol=1e-5, atol=1e-5)
+        for a, b in zip(res[0][1], other[1]):
+            close(a, b, tol)
+        close(res[0][2], other[2], tol)
+
+
+def test_cond_flow_training_tiny_upstream_gradient(tnf):
+    """Upstream gradients of 1e-9 (huge batches, loss scaling): the backward rescales them by a power of two
+    before the f16 split, so nothing underflows."""
+    nf, cde = _make(tnf, 32, 1, 2, 15, 4, [32], 9)
+    x = torch.randn(200, 4, device="cuda")
+    z = torch.randn(200, 1, 32, device="cuda")
+    grads = []
+    for scale in (1.0, 1e-9):
+        cde.zero_grad()
+        (cde.log_prob(z, x).sum() * scale).backward()
+        grads.append([p.grad.clone() / scale for p in cde.param_net.parameters()])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())

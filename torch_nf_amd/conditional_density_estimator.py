@@ -112,9 +112,6 @@ class ConditionalDensityEstimator(torch.nn.Module):
             return False
         if z.dtype != torch.float32 or x.dtype != torch.float32 or last.weight.dtype != torch.float32:
             return False
-        if torch.is_grad_enabled() and (z.requires_grad or x.requires_grad
-                                        or any(p.requires_grad for p in self.param_net.parameters())):
-            return False  # training goes through the materialised path (autograd kernels)
         return ops.cond_flow_supported(nf.D, nf.num_stages, nf.num_layers, nf.num_units, last.in_features)
 
     def log_prob(self, z, x):
@@ -127,8 +124,14 @@ class ConditionalDensityEstimator(torch.nn.Module):
             xd = x if x.device == weight.device else x.to(weight.device)
             h = self.param_net[:-1](xd) if len(self.param_net) > 1 else xd
             mean, alpha = nf._bn_stats(_lib.require_device())
-            lp, _, _ = ops.cond_flow_log_prob_raw(z[:, 0, :], h, weight, last.bias, mean, alpha, nf.D,
+            if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad or weight.requires_grad
+                                            or last.bias.requires_grad):
+                # training: forward keeps activations, hand-written backward (BatchNorm stats constant)
+                lp = ops.cond_flow_log_prob_train(z[:, 0, :], h, weight, last.bias, mean, alpha, nf.D,
                                                   nf.num_stages, nf.num_layers, nf.num_units)
+            else:
+                lp, _, _ = ops.cond_flow_log_prob_raw(z[:, 0, :], h, weight, last.bias, mean, alpha, nf.D,
+                                                      nf.num_stages, nf.num_layers, nf.num_units)
             lp = lp[:, None]
             return lp if lp.device == home else lp.to(home)
         params = self._params_for(x)

@@ -319,8 +319,82 @@ int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, c
     if (workspace_bytes < need)
         return fail(TNF_EWORKSPACE, "tnf_cond_flow_log_prob_f32: workspace %lld < %lld", (long long)workspace_bytes,
                     (long long)need);
-    return launch_cond_flow_log_prob(z, h, W, b, bn_mean, bn_alpha, log_prob, z0, sum_log_det, M, D, S, L, U, H, ldh,
-                                     ldw, workspace, as_stream(stream));
+    return launch_cond_flow_log_prob(z, h, W, b, bn_mean, bn_alpha, log_prob, z0, sum_log_det, nullptr, M, D, S, L, U,
+                                     H, ldh, ldw, workspace, as_stream(stream));
+}
+
+int64_t tnf_cond_flow_acts_floats(int64_t M, int32_t D, int32_t S, int32_t L) {
+    if (M < 0 || D < 2 || S < 1 || L < 1) return fail(TNF_EINVAL, "tnf_cond_flow_acts_floats: M=%lld D=%d S=%d L=%d", (long long)M, D, S, L);
+    return cond_acts_floats(M, D, S, L);
+}
+
+int64_t tnf_cond_flow_deltas_floats(int64_t M, int32_t D, int32_t S, int32_t L) {
+    if (M < 0 || D < 2 || S < 1 || L < 1) return fail(TNF_EINVAL, "tnf_cond_flow_deltas_floats: M=%lld D=%d S=%d L=%d", (long long)M, D, S, L);
+    return cond_deltas_floats(M, D, S, L);
+}
+
+int64_t tnf_cond_flow_bwd_workspace_bytes(int32_t D, int32_t S, int32_t L, int32_t U, int32_t H) {
+    if (!cond_flow_supported(D, S, L, U, H))
+        return fail(TNF_EUNSUPPORTED, "tnf_cond_flow_bwd_workspace_bytes: no kernel for D=%d S=%d L=%d U=%d H=%d", D, S, L, U, H);
+    return cond_flow_bwd_workspace(D, S, L, U, H);
+}
+
+static int cond_train_checks(const char* fn, int64_t M, int D, int S, int L, int U, int H, int64_t ldh, int64_t ldw,
+                             const void* h, const void* W, const void* ws) {
+    if (M < 0) return fail(TNF_EINVAL, "%s: M=%lld", fn, (long long)M);
+    if (!cond_flow_supported(D, S, L, U, H))
+        return fail(TNF_EUNSUPPORTED, "%s: no kernel for D=%d S=%d L=%d U=%d H=%d", fn, D, S, L, U, H);
+    if (ldh < H || ldw < H || (ldh & 3) || (ldw & 3))
+        return fail(TNF_EINVAL, "%s: ldh=%lld ldw=%lld must be multiples of 4 and >= H=%d", fn, (long long)ldh, (long long)ldw, H);
+    if (((uintptr_t)h & 15) || ((uintptr_t)W & 15) || ((uintptr_t)ws & 255))
+        return fail(TNF_EINVAL, "%s: h, W must be 16-byte and the workspace 256-byte aligned", fn);
+    return TNF_OK;
+}
+
+int tnf_cond_flow_log_prob_fwd_f32(const float* z, const float* h, const float* W, const float* b,
+                                   const float* bn_mean, const float* bn_alpha, float* log_prob, float* acts,
+                                   int64_t M, int32_t D, int32_t S, int32_t L, int32_t U, int32_t H, int64_t ldh,
+                                   int64_t ldw, void* workspace, int64_t workspace_bytes, void* stream) {
+    int rc = cond_train_checks("tnf_cond_flow_log_prob_fwd_f32", M, D, S, L, U, H, ldh, ldw, h, W, workspace);
+    if (rc) return rc;
+    if (M == 0) return TNF_OK;
+    if (!z || !h || !W || !b || !bn_mean || !bn_alpha || !log_prob || !acts || !workspace)
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_fwd_f32: NULL pointer");
+    if (((uintptr_t)z & 15) || ((uintptr_t)acts & 15))
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_fwd_f32: z and acts must be 16-byte aligned");
+    if (workspace_bytes < cond_flow_workspace(D, S, L, U, H))
+        return fail(TNF_EWORKSPACE, "tnf_cond_flow_log_prob_fwd_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)cond_flow_workspace(D, S, L, U, H));
+    return launch_cond_flow_log_prob(z, h, W, b, bn_mean, bn_alpha, log_prob, nullptr, nullptr, acts, M, D, S, L, U, H,
+                                     ldh, ldw, workspace, as_stream(stream));
+}
+
+int tnf_cond_flow_log_prob_bwd_f32(const float* g_log_prob, const float* h, const float* W, const float* b,
+                                   const float* bn_mean, const float* bn_alpha, const float* acts, float* deltas,
+                                   float* g_h, float* g_W, float* g_b, float* g_z, int64_t M, int32_t D, int32_t S,
+                                   int32_t L, int32_t U, int32_t H, int64_t ldh, int64_t ldw, int64_t ldgh,
+                                   int64_t ldgw, void* workspace, int64_t workspace_bytes, void* stream) {
+    int rc = cond_train_checks("tnf_cond_flow_log_prob_bwd_f32", M, D, S, L, U, H, ldh, ldw, h, W, workspace);
+    if (rc) return rc;
+    if (ldgh < H || ldgw < H || (ldgh & 3))
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_bwd_f32: ldgh=%lld ldgw=%lld", (long long)ldgh, (long long)ldgw);
+    if (!g_W || !g_b) return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_bwd_f32: NULL pointer");
+    if (M == 0) {
+        const int64_t P = flow_layout(D, S, L, U).total;
+        if (hipMemsetAsync(g_W, 0, (size_t)P * ldgw * sizeof(float), as_stream(stream)) != hipSuccess ||
+            hipMemsetAsync(g_b, 0, (size_t)P * sizeof(float), as_stream(stream)) != hipSuccess)
+            return fail(TNF_ELAUNCH, "tnf_cond_flow_log_prob_bwd_f32: memset failed");
+        return TNF_OK;
+    }
+    if (!g_log_prob || !h || !W || !b || !bn_mean || !bn_alpha || !acts || !deltas || !g_h || !workspace)
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_bwd_f32: NULL pointer");
+    if (((uintptr_t)acts & 15) || ((uintptr_t)deltas & 15) || ((uintptr_t)g_h & 15) || ((uintptr_t)g_z & 15))
+        return fail(TNF_EINVAL, "tnf_cond_flow_log_prob_bwd_f32: acts, deltas, g_h, g_z must be 16-byte aligned");
+    if (workspace_bytes < cond_flow_bwd_workspace(D, S, L, U, H))
+        return fail(TNF_EWORKSPACE, "tnf_cond_flow_log_prob_bwd_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)cond_flow_bwd_workspace(D, S, L, U, H));
+    return launch_cond_flow_backward(g_log_prob, h, W, b, bn_mean, bn_alpha, acts, deltas, g_h, g_W, g_b, g_z, M, D, S, L,
+                                     U, H, ldh, ldw, ldgh, ldgw, workspace, as_stream(stream));
 }
 
 int tnf_to_interval(int32_t dtype, const void* z, const float* consts, void* z_out, void* log_det, int64_t rows,

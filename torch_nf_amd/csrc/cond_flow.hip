@@ -21,104 +21,9 @@
 // into f16 halves, and the main kernel streams it through LDS (double-buffered chunks shared by the
 // workgroup's waves).  Each wave owns 16*BT contexts; the matrix pipe is the binding unit
 // (2 * H * D_params * 3 f16 flops per context), everything else rides under it.
-#include "mfma_tile.h"
-#include "tnf_common.h"
+#include "cond_tile.h"
 
 namespace tnf {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f4 cmfma32h(h8 a, h8 b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// v = hi + lo, hi = rtz_f16(v), lo = rtz_f16(v - hi)   (pairs packed into one dword each)
-__device__ __forceinline__ void csplit2(float v0, float v1, unsigned& hi, unsigned& lo) {
-    const auto h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-    const unsigned hb = __builtin_bit_cast(unsigned, h);
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(v0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(v1));
-    hi = hb;
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-}
-__device__ __forceinline__ void csplit8(f4 v0, f4 v1, h8& hi, h8& lo) {
-    unsigned a0, a1, a2, a3, b0, b1, b2, b3;
-    csplit2(v0[0], v0[1], a0, b0);
-    csplit2(v0[2], v0[3], a1, b1);
-    csplit2(v1[0], v1[1], a2, b2);
-    csplit2(v1[2], v1[3], a3, b3);
-    hi = __builtin_bit_cast(h8, (u4){a0, a1, a2, a3});
-    lo = __builtin_bit_cast(h8, (u4){b0, b1, b2, b3});
-}
-
-// ---------------------------------------------------------------------------
-// The tile program: which 16 parameter-row entries tile t holds, in consumption order.
-// ---------------------------------------------------------------------------
-struct CondCfg {
-    int D, S, L, U, H;  // H: width of the conditioner's last hidden layer (multiple of 32)
-    int DT, HT;         // 16-feature tiles of z and of one coupling half
-    int64_t TC, TS, T;  // tiles per coupling layer, per stage, in total
-    FlowLayout fl;
-};
-__host__ __device__ inline CondCfg cond_cfg(int D, int S, int L, int U, int H) {
-    CondCfg c;
-    c.D = D; c.S = S; c.L = L; c.U = U; c.H = H;
-    c.DT = D / 16;
-    c.HT = D / 32;
-    c.TC = 2 * (int64_t)(D / 2) + 2 + (int64_t)(L - 1) * (2 * U + 2) + 2 * (int64_t)U * c.HT + 2 * c.HT;
-    c.TS = 2 * c.DT + 2 * c.TC;
-    c.T = c.TS * S;
-    c.fl = flow_layout(D, S, L, U);
-    return c;
-}
-// (first parameter index, number of valid rows) of tile t
-__host__ __device__ inline void cond_tile_desc(const CondCfg& c, int64_t t, int64_t& base, int& count) {
-    const int Hd = c.D / 2, U = c.U;
-    const int stage = c.S - 1 - (int)(t / c.TS);
-    int64_t r = t % c.TS;
-    const int64_t so = (int64_t)stage * c.fl.stage;
-    if (r < 2 * c.DT) {  // Affine: [alpha tile, shift tile] per 16 features
-        base = so + c.fl.p_up + c.fl.p_low + (r & 1) * c.D + 16 * (r >> 1);
-        count = 16;
-        return;
-    }
-    r -= 2 * c.DT;
-    int64_t off = so + c.fl.p_up;  // RealNVP(lower) first in the inverse pass
-    if (r >= c.TC) {
-        r -= c.TC;
-        off = so;
-    }
-    const int64_t n0 = 2 * (int64_t)Hd + 2;
-    if (r < n0) {  // layer 0: Hd -> U
-        count = U;
-        if (r < 2 * Hd) base = off + (r & 1) * (int64_t)Hd * U + (r >> 1) * U;
-        else base = off + 2 * (int64_t)Hd * U + (r - 2 * Hd) * U;
-        return;
-    }
-    r -= n0;
-    off += 2 * (int64_t)Hd * U + 2 * U;
-    const int64_t nh = 2 * (int64_t)U + 2;
-    if (r < (c.L - 1) * nh) {  // hidden layers: U -> U
-        off += (r / nh) * (2 * (int64_t)U * U + 2 * U);
-        r %= nh;
-        count = U;
-        if (r < 2 * U) base = off + (r & 1) * (int64_t)U * U + (r >> 1) * U;
-        else base = off + 2 * (int64_t)U * U + (r - 2 * U) * U;
-        return;
-    }
-    r -= (c.L - 1) * nh;
-    off += (c.L - 1) * (2 * (int64_t)U * U + 2 * U);
-    count = 16;  // output layer: U -> Hd, Hd a multiple of 16
-    if (r < 2 * (int64_t)U * c.HT) {
-        const int64_t k = r / (2 * c.HT), rem = r % (2 * c.HT);
-        base = off + (rem & 1) * (int64_t)U * Hd + k * Hd + 16 * (rem >> 1);
-    } else {
-        r -= 2 * (int64_t)U * c.HT;
-        base = off + 2 * (int64_t)U * Hd + (r & 1) * Hd + 16 * (r >> 1);
-    }
-}
 
 // ---------------------------------------------------------------------------
 // Prep 1: largest magnitude of W_last / b_last (operand scaling keeps the f16 halves normal).
@@ -138,19 +43,13 @@ cond_absmax_kernel(const float* __restrict__ W, const float* __restrict__ b, int
     if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));  // non-negative floats order like uints
 }
 
-// power-of-two scale that brings the largest magnitude just below 2^14 (f16 max is 65504)
-__device__ __forceinline__ float cond_scale(unsigned maxbits) {
-    const float mx = __uint_as_float(maxbits);
-    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
-    return ldexpf(1.f, 13 - ilogbf(mx));
-}
-
 // Prep 2: the operand image.  Tile t = [ks][part hi/lo][lane] 16-byte groups (the lane's 8 f16 of row
 // lane&15, k = 32ks + 8(lane>>4) .. +7) followed by the 16 scaled biases (fp32).
 template <int KS>
 __global__ void __launch_bounds__(256)
 cond_image_kernel(const float* __restrict__ W, const float* __restrict__ b, int64_t ldw, CondCfg cfg,
-                  const unsigned* __restrict__ maxbits, float* __restrict__ inv_scale, u4* __restrict__ image) {
+                  const unsigned* __restrict__ maxbits, float* __restrict__ inv_scale, u4* __restrict__ image,
+                  int backward_order) {
     constexpr int TILE_U4 = KS * 128 + 4;
     const float scale = cond_scale(*maxbits);
     if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = 1.f / scale;
@@ -159,7 +58,8 @@ cond_image_kernel(const float* __restrict__ W, const float* __restrict__ b, int6
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < cfg.T; t += (int64_t)gridDim.x * 4) {
         int64_t base;
         int count;
-        cond_tile_desc(cfg, t, base, count);
+        if (backward_order) cond_tile_desc_bwd(cfg, t, base, count);
+        else cond_tile_desc(cfg, t, base, count);
         const bool ok = r < count;
         const float* wr = W + (base + (ok ? r : 0)) * ldw;
         u4* tp = image + t * TILE_U4;
@@ -192,89 +92,21 @@ struct CondArgs {
     float* log_prob;        // (M)
     float* z0;              // (M, D) or NULL
     float* sum_log_det;     // (M) or NULL
+    // training mode (SAVE): what the backward kernels need, slot-major so that a wave's contexts are
+    // contiguous.  acts_aff [S][M][D]: state after Affine^-1 + BN^-1 of each stage (compute order);
+    // acts_c [2S][M][CR]: per coupling layer [x1 (D/2) | x2_out (D/2) | s (D/2) | (h_t 16, h_s 16) x L]
+    float* acts_aff;
+    float* acts_c;
     int64_t M, ldh, T;
     int S, L, U;
 };
 
-// the workgroup's view of the image: chunks of G tiles, double-buffered in LDS
-template <int KS, int G, int NTHREADS>
-struct TileStream {
-    static constexpr int TILE_U4 = KS * 128 + 4;
-    static constexpr int CHUNK_U4 = G * TILE_U4;
-    static constexpr int PF = (CHUNK_U4 + NTHREADS - 1) / NTHREADS;
-    const u4* img;
-    u4* stg;
-    int64_t total_u4;
-    int t;
-    u4 pf[PF];
-
-    __device__ __forceinline__ void fetch(int chunk) {
-        const int64_t base = (int64_t)chunk * CHUNK_U4;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            int64_t g = base + threadIdx.x + i * NTHREADS;
-            g = g < total_u4 ? g : total_u4 - 1;  // clamped, never predicated (see ld_sel)
-            pf[i] = img[g];
-        }
-    }
-    __device__ __forceinline__ void commit(int chunk) {
-        u4* dst = stg + (chunk & 1) * CHUNK_U4;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int idx = threadIdx.x + i * NTHREADS;
-            if (idx < CHUNK_U4) dst[idx] = pf[i];
-        }
-    }
-    __device__ __forceinline__ void init(const u4* image, u4* stage, int64_t tiles) {
-        img = image;
-        stg = stage;
-        total_u4 = tiles * TILE_U4;
-        t = 0;
-        fetch(0);
-        commit(0);
-        __syncthreads();
-        fetch(1);
-    }
-    // every wave of the workgroup calls next() the same number of times, in the same order
-    __device__ __forceinline__ const u4* next() {
-        const int chunk = t / G, in = t - chunk * G;
-        if (in == 0 && t > 0) {
-            commit(chunk);   // safe: all waves left chunk-2 (same buffer) before the previous barrier
-            __syncthreads();
-            fetch(chunk + 1);
-        }
-        ++t;
-        return stg + (chunk & 1) * CHUNK_U4 + in * TILE_U4;
-    }
-};
-
-template <int KS, int BT>
-__device__ __forceinline__ void tile_gemm(const u4* tp, int lane, const h8 (&bh)[BT][KS], const h8 (&bl)[BT][KS],
-                                          f4 (&P)[BT]) {
-    const f4 c0 = *reinterpret_cast<const f4*>(tp + KS * 128 + (lane >> 4));
-#pragma unroll
-    for (int bt = 0; bt < BT; ++bt) P[bt] = c0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const h8 ah = __builtin_bit_cast(h8, tp[(ks * 2 + 0) * 64 + lane]);
-        const h8 al = __builtin_bit_cast(h8, tp[(ks * 2 + 1) * 64 + lane]);
-#pragma unroll
-        for (int bt = 0; bt < BT; ++bt) P[bt] = cmfma32h(ah, bh[bt][ks], P[bt]);
-#pragma unroll
-        for (int bt = 0; bt < BT; ++bt) P[bt] = cmfma32h(ah, bl[bt][ks], P[bt]);
-#pragma unroll
-        for (int bt = 0; bt < BT; ++bt) P[bt] = cmfma32h(al, bh[bt][ks], P[bt]);
-    }
-}
-
-template <int KS> constexpr int kCondG = 8 / KS;  // tiles per LDS chunk (~16.5 KB)
-
-template <int DT, int KS, int BT, int NW>
+template <int DT, int KS, int BT, int NW, bool SAVE>
 __global__ void __launch_bounds__(64 * NW)
 cond_flow_kernel(CondArgs a) {
     constexpr int D = 16 * DT, Hd = D / 2, HT = DT / 2;
     constexpr int ZS = D + 4, HS = 20, CT = 16 * BT;
-    typedef TileStream<KS, kCondG<KS>, 64 * NW> Stream;
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> Stream;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u4* stage = reinterpret_cast<u4*>(smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -314,9 +146,15 @@ cond_flow_kernel(CondArgs a) {
     for (int bt = 0; bt < BT; ++bt) ld[bt] = 0.f;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     const int U = a.U;
+    const int CR = 3 * Hd + 32 * a.L;  // floats per saved coupling record
+    bool live[BT];                     // context exists (the tail wave carries clamped duplicates)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) live[bt] = m0 + bt * 16 + c < a.M;
 
     // one RealNVP layer, inverse direction (bijectors.py:183-206): z2 <- (z2 - t(z1)) / exp(s(z1))
-    auto coupling = [&](int cond_off, int tr_off) {
+    auto coupling = [&](int cond_off, int tr_off, int slot) {
+        // saved record of this layer for context (bt, c); only dereferenced when SAVE
+        auto rec = [&](int bt) -> float* { return a.acts_c + ((int64_t)slot * a.M + m0 + bt * 16 + c) * CR; };
         f4 at[BT], as[BT], Pt[BT], Ps[BT];
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) at[bt] = as[bt] = zero;
@@ -336,10 +174,22 @@ cond_flow_kernel(CondArgs a) {
         for (int bt = 0; bt < BT; ++bt) {
             at[bt] += inv * Pt[bt];
             as[bt] += inv * Ps[bt];
+            f4 ht4, hs4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                hbt[(bt * 16 + c) * HS + 4 * q + j] = tanhf(at[bt][j]);
-                hbs[(bt * 16 + c) * HS + 4 * q + j] = tanhf(as[bt][j]);
+                ht4[j] = tanhf(at[bt][j]);
+                hs4[j] = tanhf(as[bt][j]);
+            }
+            *reinterpret_cast<f4*>(hbt + (bt * 16 + c) * HS + 4 * q) = ht4;
+            *reinterpret_cast<f4*>(hbs + (bt * 16 + c) * HS + 4 * q) = hs4;
+            if (SAVE && live[bt]) {
+                float* r = rec(bt);
+#pragma unroll
+                for (int t = 0; t < HT; ++t)  // conditioning half, unchanged by this layer
+                    *reinterpret_cast<f4*>(r + 16 * t + 4 * q) =
+                        *reinterpret_cast<const f4*>(zb + (bt * 16 + c) * ZS + cond_off + 16 * t + 4 * q);
+                *reinterpret_cast<f4*>(r + 3 * Hd + 4 * q) = ht4;
+                *reinterpret_cast<f4*>(r + 3 * Hd + 16 + 4 * q) = hs4;
             }
         }
         for (int l = 1; l < a.L; ++l) {
@@ -360,10 +210,18 @@ cond_flow_kernel(CondArgs a) {
             for (int bt = 0; bt < BT; ++bt) {
                 at[bt] += inv * Pt[bt];
                 as[bt] += inv * Ps[bt];
+                f4 ht4, hs4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    hbt[(bt * 16 + c) * HS + 4 * q + j] = tanhf(at[bt][j]);
-                    hbs[(bt * 16 + c) * HS + 4 * q + j] = tanhf(as[bt][j]);
+                    ht4[j] = tanhf(at[bt][j]);
+                    hs4[j] = tanhf(as[bt][j]);
+                }
+                *reinterpret_cast<f4*>(hbt + (bt * 16 + c) * HS + 4 * q) = ht4;
+                *reinterpret_cast<f4*>(hbs + (bt * 16 + c) * HS + 4 * q) = hs4;
+                if (SAVE && live[bt]) {
+                    float* r = rec(bt) + 3 * Hd + 32 * l;
+                    *reinterpret_cast<f4*>(r + 4 * q) = ht4;
+                    *reinterpret_cast<f4*>(r + 16 + 4 * q) = hs4;
                 }
             }
         }
@@ -406,6 +264,11 @@ cond_flow_kernel(CondArgs a) {
                     ld[bt] += s4[j];
                 }
                 *zp = zv;
+                if (SAVE && live[bt]) {
+                    float* r = rec(bt);
+                    *reinterpret_cast<f4*>(r + Hd + 16 * o + 4 * q) = zv;
+                    *reinterpret_cast<f4*>(r + 2 * Hd + 16 * o + 4 * q) = s4;
+                }
             }
         }
     };
@@ -437,10 +300,12 @@ cond_flow_kernel(CondArgs a) {
                     }
                     ld[bt] -= lal;
                     *zp = zv;
+                    if (SAVE && live[bt])
+                        *reinterpret_cast<f4*>(a.acts_aff + ((int64_t)si * a.M + m0 + bt * 16 + c) * D + 16 * t + 4 * q) = zv;
                 }
             }
         }
-        coupling(Hd, 0);  // RealNVP(transform_upper=False): conditions on the upper half
+        coupling(Hd, 0, 2 * si);  // RealNVP(transform_upper=False): conditions on the upper half
         {   // BatchNorm^-1 of layer 2*stage
             const float* bnA = a.bn_alpha + (int64_t)(2 * stg_i) * D;
             const float* bnM = a.bn_mean + (int64_t)(2 * stg_i) * D;
@@ -459,7 +324,7 @@ cond_flow_kernel(CondArgs a) {
                 }
             }
         }
-        coupling(0, Hd);  // RealNVP(transform_upper=True)
+        coupling(0, Hd, 2 * si + 1);  // RealNVP(transform_upper=True)
     }
 
     // ---- log q = -|z0|^2/2 - D log sqrt(2 pi) - sum log_det (density_estimator.py:413-416) ----
@@ -503,12 +368,12 @@ int64_t cond_flow_workspace(int D, int S, int L, int U, int H) {
     return 256 + cond_image_bytes(cond_cfg(D, S, L, U, H));
 }
 
-template <int DT, int KS, int BT, int NW>
+template <int DT, int KS, int BT, int NW, bool SAVE>
 static int launch_cond_variant(const CondArgs& a, hipStream_t st) {
-    typedef TileStream<KS, kCondG<KS>, 64 * NW> Stream;
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> Stream;
     constexpr int D = 16 * DT;
     const size_t smem = (size_t)2 * Stream::CHUNK_U4 * 16 + (size_t)NW * 16 * BT * (D + 4 + 40) * 4;
-    auto k = cond_flow_kernel<DT, KS, BT, NW>;
+    auto k = cond_flow_kernel<DT, KS, BT, NW, SAVE>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int64_t per_wg = (int64_t)NW * 16 * BT;
@@ -524,29 +389,48 @@ template <int DT, int KS>
 static int launch_cond_dk(const CondArgs& a, hipStream_t st) {
     int v = g_cond_variant;
     if (v == 0) v = a.M >= 256 * 256 ? 3 : (a.M >= 256 * 128 ? 2 : 1);
-    if (v == 3) return launch_cond_variant<DT, KS, 2, 8>(a, st);
-    if (v == 2) return launch_cond_variant<DT, KS, 1, 8>(a, st);
-    return launch_cond_variant<DT, KS, 1, 4>(a, st);
+    if (a.acts_c) {  // training forward: two shapes only (compile time)
+        if (v >= 2) return launch_cond_variant<DT, KS, 2, 8, true>(a, st);
+        return launch_cond_variant<DT, KS, 1, 4, true>(a, st);
+    }
+    if (v == 3) return launch_cond_variant<DT, KS, 2, 8, false>(a, st);
+    if (v == 2) return launch_cond_variant<DT, KS, 1, 8, false>(a, st);
+    return launch_cond_variant<DT, KS, 1, 4, false>(a, st);
+}
+
+// absmax -> power-of-two scale (ws[0]: max bits, ws[1]: 1/scale) and the operand image in forward or
+// backward tile order
+int launch_cond_image(const float* W, const float* b, int64_t ldw, const CondCfg& cfg, void* ws, void* image,
+                      int backward_order, hipStream_t st) {
+    unsigned* maxbits = reinterpret_cast<unsigned*>(ws);
+    float* inv_scale = reinterpret_cast<float*>(ws) + 1;
+    u4* img = reinterpret_cast<u4*>(image);
+    if (hipMemsetAsync(maxbits, 0, 8, st) != hipSuccess) return fail(TNF_ELAUNCH, "cond_flow: memset failed");
+    hipLaunchKernelGGL(cond_absmax_kernel, dim3(256), dim3(256), 0, st, W, b, cfg.fl.total, cfg.H, ldw, maxbits);
+    const unsigned ib = (unsigned)((cfg.T + 3) / 4);
+    if (cfg.H == 32)
+        hipLaunchKernelGGL(cond_image_kernel<1>, dim3(ib), dim3(256), 0, st, W, b, ldw, cfg, maxbits, inv_scale, img, backward_order);
+    else if (cfg.H == 64)
+        hipLaunchKernelGGL(cond_image_kernel<2>, dim3(ib), dim3(256), 0, st, W, b, ldw, cfg, maxbits, inv_scale, img, backward_order);
+    else
+        hipLaunchKernelGGL(cond_image_kernel<4>, dim3(ib), dim3(256), 0, st, W, b, ldw, cfg, maxbits, inv_scale, img, backward_order);
+    return check_launch("cond_flow_prep");
 }
 
 int launch_cond_flow_log_prob(const float* z, const float* h, const float* W, const float* b, const float* bn_mean,
-                              const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, int64_t M, int D,
-                              int S, int L, int U, int H, int64_t ldh, int64_t ldw, void* ws, hipStream_t st) {
+                              const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, float* acts,
+                              int64_t M, int D, int S, int L, int U, int H, int64_t ldh, int64_t ldw, void* ws,
+                              hipStream_t st) {
     const CondCfg cfg = cond_cfg(D, S, L, U, H);
-    unsigned* maxbits = reinterpret_cast<unsigned*>(ws);
     float* inv_scale = reinterpret_cast<float*>(ws) + 1;
     u4* image = reinterpret_cast<u4*>(reinterpret_cast<char*>(ws) + 256);
-    if (hipMemsetAsync(maxbits, 0, 8, st) != hipSuccess) return fail(TNF_ELAUNCH, "cond_flow: memset failed");
-    hipLaunchKernelGGL(cond_absmax_kernel, dim3(256), dim3(256), 0, st, W, b, cfg.fl.total, H, ldw, maxbits);
-    const unsigned ib = (unsigned)((cfg.T + 3) / 4);
-    if (H == 32) hipLaunchKernelGGL(cond_image_kernel<1>, dim3(ib), dim3(256), 0, st, W, b, ldw, cfg, maxbits, inv_scale, image);
-    else if (H == 64) hipLaunchKernelGGL(cond_image_kernel<2>, dim3(ib), dim3(256), 0, st, W, b, ldw, cfg, maxbits, inv_scale, image);
-    else hipLaunchKernelGGL(cond_image_kernel<4>, dim3(ib), dim3(256), 0, st, W, b, ldw, cfg, maxbits, inv_scale, image);
-    int rc = check_launch("cond_flow_prep");
+    int rc = launch_cond_image(W, b, ldw, cfg, ws, image, 0, st);
     if (rc) return rc;
     CondArgs a;
     a.z = z; a.h = h; a.image = image; a.inv_scale = inv_scale; a.bn_mean = bn_mean; a.bn_alpha = bn_alpha;
     a.log_prob = log_prob; a.z0 = z0; a.sum_log_det = sum_log_det;
+    a.acts_aff = acts;
+    a.acts_c = acts ? acts + (int64_t)S * M * D : nullptr;
     a.M = M; a.ldh = ldh; a.T = cfg.T; a.S = S; a.L = L; a.U = U;
     if (D == 64) {
         if (H == 32) return launch_cond_dk<4, 1>(a, st);

@@ -1,0 +1,678 @@
+// Backward of the fused conditioner + flow (cond_flow.hip), for SNPE / APT training:
+//   loss -> g_log_prob (M)  ==>  g_W_last (D_params, H), g_b_last (D_params), g_h (M, H)  [, g_z (M, D)]
+// with params[m] = W_last h[m] + b_last never materialised, and neither their gradient
+// gP[m, (k,o)] = x[m,k] * delta[m,o] (82 KB per context each).  Two kernels:
+//
+// 1. cond_flow_bwd_kernel walks the flow back (stages 0..S-1: RealNVP(up), BN, RealNVP(low), Affine) for
+//    16*BT contexts per wave.  The per-context weights are regenerated tile by tile exactly as in the
+//    forward (P = Wtile . h^T, split-f16 MFMA) and used once, for delta propagation (gx[k] = sum_o P[k,o]
+//    delta[o]).  In the same sweep the conditioner gradient g_h[m,:] = sum_p gP[m,p] W[p,:] is
+//    accumulated on the matrix pipe from the TRANSPOSED operand image (rows = hidden unit j, K = the 32
+//    parameters of a [t net, s net] tile pair) against B = x_k * delta, built in registers.
+//    Activations come from the records the training forward saved (CondArgs::acts_*); the deltas of
+//    every layer are written out (6 KB per context) for kernel 2.
+// 2. cond_gw_kernel: g_W[(k,o), j] = sum_m x[m,k] delta[m,o] h[m,j] -- a reduction over contexts, so it is
+//    parallelised over parameter tiles (one workgroup = one (layer, net, 16-output tile) x a slice of the
+//    contexts; its waves share the staged x / delta / h chunk and each owns a few input units k), with
+//    no atomics beyond the final few-way merge of the context slices.
+// MFMA work: kernel 1 = 2x the forward, kernel 2 = 1x.
+#include "cond_tile.h"
+
+namespace tnf {
+
+// ---------------------------------------------------------------------------
+// Transposed image, backward tile order, per PAIR of tiles: [jt < H/16][part hi/lo][lane] 16-byte groups;
+// lane (j = lane & 15, q = lane >> 4) holds W[param(8q + e)][16 jt + j], e = 0..7, where params 0..15
+// are the rows of the pair's first tile and 16..31 those of the second.
+// ---------------------------------------------------------------------------
+template <int KS>
+__global__ void __launch_bounds__(256)
+cond_timage_kernel(const float* __restrict__ W, int64_t ldw, CondCfg cfg, const unsigned* __restrict__ maxbits,
+                   u4* __restrict__ image) {
+    constexpr int JT = 2 * KS, PAIR_U4 = KS * 256;
+    const float scale = cond_scale(*maxbits);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + wave; p < cfg.T / 2; p += (int64_t)gridDim.x * 4) {
+        int64_t base;
+        int count;
+        cond_tile_desc_bwd(cfg, 2 * p + (q >> 1), base, count);
+        u4* tp = image + p * PAIR_U4;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * (q & 1) + e;
+                const bool ok = r < count;
+                const float w = W[(base + (ok ? r : 0)) * ldw + 16 * jt + j];
+                v[e] = ok ? w * scale : 0.f;
+            }
+            h8 hi, lo;
+            csplit8((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, hi, lo);
+            tp[(jt * 2 + 0) * 64 + lane] = __builtin_bit_cast(u4, hi);
+            tp[(jt * 2 + 1) * 64 + lane] = __builtin_bit_cast(u4, lo);
+        }
+    }
+}
+
+// Upstream gradients are typically 1/M-sized; all of the backward is linear in them, so it runs on
+// g_lp * 2^k with max |g_lp| 2^k in [8, 16) -- keeps the f16 halves of x*delta normal -- and every
+// output is multiplied by 2^-k at the end.
+__device__ __forceinline__ float cond_gscale(unsigned maxbits) {
+    const float mx = __uint_as_float(maxbits);
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
+    return ldexpf(1.f, 3 - ilogbf(mx));
+}
+
+struct CondBwdArgs {
+    const float* g_lp;      // (M)
+    const unsigned* gmaxbits;  // bits of max |g_lp|
+    const float* h;         // (M, ldh)
+    const u4* pimg;         // forward-layout tiles in backward order
+    const u4* timg;         // transposed pairs in backward order
+    const float* inv_scale;
+    const float* bn_mean;
+    const float* bn_alpha;
+    const float* acts_aff;  // [S][M][D]
+    const float* acts_c;    // [2S][M][CR]
+    float* d_aff;           // [S][M][2D]    g_alpha | g_shift per context
+    float* d_c;             // [2S][M][DR]   [delta_out t (D/2) | s (D/2) | (delta_t 16, delta_s 16) x L levels]
+    float* g_h;             // (M, ldgh)
+    float* g_z;             // (M, D) or NULL
+    int64_t M, ldh, ldgh, T;
+    int S, L, U;
+};
+
+__device__ __forceinline__ float dot4(f4 a, f4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+// lane (c, q) gets elements 8(q&1) .. 8(q&1)+7 of context c's 16-vector of net (q >> 1); the vector lives
+// 4 per lane in the MFMA output layout (lane (c, q') holds 4q' .. 4q'+3)
+__device__ __forceinline__ void gather8(f4 vt, f4 vs, int c, int q, float (&out)[8]) {
+    const int srcA = c + 32 * (q & 1), srcB = srcA + 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t0 = __shfl(vt[j], srcA), s0 = __shfl(vs[j], srcA);
+        const float t1 = __shfl(vt[j], srcB), s1 = __shfl(vs[j], srcB);
+        out[j] = q < 2 ? t0 : s0;
+        out[4 + j] = q < 2 ? t1 : s1;
+    }
+}
+
+template <int DT, int KS, int BT, int NW>
+__global__ void __launch_bounds__(64 * NW)
+cond_flow_bwd_kernel(CondBwdArgs a) {
+    constexpr int D = 16 * DT, Hd = D / 2, HT = DT / 2, JT = 2 * KS;
+    constexpr int ZS = D + 4, CT = 16 * BT;
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> PStream;
+    typedef TileStream<KS * 256, 4 / KS, 64 * NW> TStream;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u4* pstage = reinterpret_cast<u4*>(smem_raw);
+    u4* tstage = pstage + 2 * PStream::CHUNK_U4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    float* gzb = reinterpret_cast<float*>(tstage + 2 * TStream::CHUNK_U4) + wave * (CT * ZS);  // [CT][ZS] g_z
+
+    const int64_t m0 = ((int64_t)blockIdx.x * NW + wave) * CT;
+    const int CR = 3 * Hd + 32 * a.L, DR = 2 * Hd + 32 * a.L;
+    const int U = a.U;
+    const float gsc = cond_gscale(*a.gmaxbits);
+    int64_t mrow[BT];
+    bool live[BT];
+    float glp[BT];
+    h8 bh[BT][KS], bl[BT][KS];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        const int64_t m = m0 + bt * 16 + c;
+        live[bt] = m < a.M;
+        mrow[bt] = live[bt] ? m : a.M - 1;
+        glp[bt] = live[bt] ? a.g_lp[mrow[bt]] * gsc : 0.f;
+        const float* hr = a.h + mrow[bt] * a.ldh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            csplit8(*reinterpret_cast<const f4*>(hr + 32 * ks + 8 * q),
+                    *reinterpret_cast<const f4*>(hr + 32 * ks + 8 * q + 4), bh[bt][ks], bl[bt][ks]);
+    }
+    {   // g_z0 = -g_lp * z0; z0 = [x1 | x2_out] of the coupling layer computed last (slot 2(S-1)+1, upper)
+        const int slot = 2 * (a.S - 1) + 1;
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            const float* r = a.acts_c + ((int64_t)slot * a.M + mrow[bt]) * CR;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const f4 v = *reinterpret_cast<const f4*>(r + 16 * t + 4 * q);  // x1 (Hd) then x2_out (Hd)
+                *reinterpret_cast<f4*>(gzb + (bt * 16 + c) * ZS + 16 * t + 4 * q) = -glp[bt] * v;
+            }
+        }
+    }
+    const float inv = *a.inv_scale;
+    PStream ps;
+    TStream tq;
+    ps.init(a.pimg, pstage, a.T);
+    tq.init(a.timg, tstage, a.T / 2);
+
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 gacc[BT][JT];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) gacc[bt][jt] = zero;
+
+    // g_h += Wpair^T (H x 32 params) . B (32 params x 16 contexts), B = xsel * d8 per lane
+    auto pair_gh = [&](const float (&xsel)[BT], const float (&d8)[BT][8]) {
+        const u4* tp = tq.next();
+        h8 Bh[BT], Bl[BT];
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            const float x = xsel[bt];
+            csplit8((f4){x * d8[bt][0], x * d8[bt][1], x * d8[bt][2], x * d8[bt][3]},
+                    (f4){x * d8[bt][4], x * d8[bt][5], x * d8[bt][6], x * d8[bt][7]}, Bh[bt], Bl[bt]);
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const h8 ah = __builtin_bit_cast(h8, tp[(jt * 2 + 0) * 64 + lane]);
+            const h8 al = __builtin_bit_cast(h8, tp[(jt * 2 + 1) * 64 + lane]);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) gacc[bt][jt] = cmfma32h(ah, Bh[bt], gacc[bt][jt]);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) gacc[bt][jt] = cmfma32h(al, Bh[bt], gacc[bt][jt]);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) gacc[bt][jt] = cmfma32h(ah, Bl[bt], gacc[bt][jt]);
+        }
+    };
+    float ones[BT];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) ones[bt] = 1.f;
+
+    auto coupling_bwd = [&](int cond_off, int tr_off, int slot) {
+        const float* rec[BT];
+        float* drec[BT];
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            rec[bt] = a.acts_c + ((int64_t)slot * a.M + mrow[bt]) * CR;
+            drec[bt] = a.d_c + ((int64_t)slot * a.M + mrow[bt]) * DR;
+        }
+        // ---- through x2_out = (x2_in - t) e^-s and log_det += sum s ----
+        f4 dt[HT][BT], ds[HT][BT];
+        float d8o[HT][BT][8];
+#pragma unroll
+        for (int o = 0; o < HT; ++o)
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                f4* gp = reinterpret_cast<f4*>(gzb + (bt * 16 + c) * ZS + tr_off + 16 * o + 4 * q);
+                const f4 g = *gp;
+                const f4 x2 = *reinterpret_cast<const f4*>(rec[bt] + Hd + 16 * o + 4 * q);
+                const f4 s4 = *reinterpret_cast<const f4*>(rec[bt] + 2 * Hd + 16 * o + 4 * q);
+                f4 gn, vt, vs;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = expf(-s4[j]);
+                    vt[j] = -e * g[j];
+                    vs[j] = -x2[j] * g[j] - glp[bt];
+                    gn[j] = e * g[j];
+                }
+                *gp = gn;
+                dt[o][bt] = vt;
+                ds[o][bt] = vs;
+                if (live[bt]) {
+                    *reinterpret_cast<f4*>(drec[bt] + 16 * o + 4 * q) = vt;
+                    *reinterpret_cast<f4*>(drec[bt] + Hd + 16 * o + 4 * q) = vs;
+                }
+                gather8(vt, vs, c, q, d8o[o][bt]);
+            }
+        // ---- output layer: U -> Hd; its inputs are the activations of hidden level L-1 ----
+        f4 dht[BT], dhs[BT], Pt[BT], Ps[BT];
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) dht[bt] = dhs[bt] = zero;
+        {
+            const int aoff = 3 * Hd + 32 * (a.L - 1);
+            for (int k = 0; k < U; ++k) {
+                float xt[BT], xs[BT], xsel[BT], pt[BT], pss[BT];
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    xt[bt] = rec[bt][aoff + k];
+                    xs[bt] = rec[bt][aoff + 16 + k];
+                    xsel[bt] = q < 2 ? xt[bt] : xs[bt];
+                    pt[bt] = pss[bt] = 0.f;
+                }
+#pragma unroll
+                for (int o = 0; o < HT; ++o) {
+                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pt);
+                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Ps);
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) {
+                        pt[bt] += dot4(Pt[bt], dt[o][bt]);
+                        pss[bt] += dot4(Ps[bt], ds[o][bt]);
+                    }
+                    pair_gh(xsel, d8o[o]);
+                }
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    const float vt = reduce_q(pt[bt]) * inv * (1.f - xt[bt] * xt[bt]);
+                    const float vs = reduce_q(pss[bt]) * inv * (1.f - xs[bt] * xs[bt]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool mine = k == 4 * q + j;
+                        dht[bt][j] = mine ? vt : dht[bt][j];
+                        dhs[bt][j] = mine ? vs : dhs[bt][j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < HT; ++o) {  // output-layer biases: gP = delta
+                ps.next();
+                ps.next();
+                pair_gh(ones, d8o[o]);
+            }
+        }
+        // ---- hidden layers L-1 .. 1 (U -> U), then layer 0 (Hd -> U) ----
+        for (int l = a.L - 1; l >= 0; --l) {
+            float d8[BT][8];
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                if (live[bt]) {
+                    *reinterpret_cast<f4*>(drec[bt] + 2 * Hd + 32 * l + 4 * q) = dht[bt];
+                    *reinterpret_cast<f4*>(drec[bt] + 2 * Hd + 32 * l + 16 + 4 * q) = dhs[bt];
+                }
+                gather8(dht[bt], dhs[bt], c, q, d8[bt]);
+            }
+            if (l > 0) {
+                f4 nt[BT], ns[BT];
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) nt[bt] = ns[bt] = zero;
+                const int aoff = 3 * Hd + 32 * (l - 1);
+                for (int k = 0; k < U; ++k) {
+                    float xt[BT], xs[BT], xsel[BT];
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) {
+                        xt[bt] = rec[bt][aoff + k];
+                        xs[bt] = rec[bt][aoff + 16 + k];
+                        xsel[bt] = q < 2 ? xt[bt] : xs[bt];
+                    }
+                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pt);
+                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Ps);
+                    pair_gh(xsel, d8);
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) {
+                        const float vt = reduce_q(dot4(Pt[bt], dht[bt])) * inv * (1.f - xt[bt] * xt[bt]);
+                        const float vs = reduce_q(dot4(Ps[bt], dhs[bt])) * inv * (1.f - xs[bt] * xs[bt]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool mine = k == 4 * q + j;
+                            nt[bt][j] = mine ? vt : nt[bt][j];
+                            ns[bt][j] = mine ? vs : ns[bt][j];
+                        }
+                    }
+                }
+                ps.next();
+                ps.next();
+                pair_gh(ones, d8);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    dht[bt] = nt[bt];
+                    dhs[bt] = ns[bt];
+                }
+            } else {
+                for (int k = 0; k < Hd; ++k) {
+                    float x[BT];
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) x[bt] = rec[bt][k];  // x1: the same input for both nets
+                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pt);
+                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Ps);
+                    pair_gh(x, d8);
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) {
+                        const float g = reduce_q(dot4(Pt[bt], dht[bt]) + dot4(Ps[bt], dhs[bt])) * inv;
+                        if (q == 0) gzb[(bt * 16 + c) * ZS + cond_off + k] += g;
+                    }
+                }
+                ps.next();
+                ps.next();
+                pair_gh(ones, d8);
+            }
+        }
+    };
+
+    for (int stage = 0; stage < a.S; ++stage) {
+        const int si = a.S - 1 - stage;  // the forward's compute index of this stage
+        coupling_bwd(0, Hd, 2 * si + 1);  // RealNVP(transform_upper=True), computed last in the stage
+        {   // BatchNorm^-1 of layer 2*stage: z_out = z_in * alpha + mean
+            const float* bnA = a.bn_alpha + (int64_t)(2 * stage) * D;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const f4 al = *reinterpret_cast<const f4*>(bnA + 16 * t + 4 * q);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    f4* gp = reinterpret_cast<f4*>(gzb + (bt * 16 + c) * ZS + 16 * t + 4 * q);
+                    *gp = *gp * al;
+                }
+            }
+        }
+        coupling_bwd(Hd, 0, 2 * si);
+        {   // z_out = (z_in - shift) e^-a alpha_bn + mean_bn;  log_det += a
+            const float* bnA = a.bn_alpha + (int64_t)(2 * stage + 1) * D;
+            const float* bnM = a.bn_mean + (int64_t)(2 * stage + 1) * D;
+            f4 Pa[BT];
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pa);
+                ps.next();  // the shift tile: its values are not needed backwards
+                const f4 al = *reinterpret_cast<const f4*>(bnA + 16 * t + 4 * q);
+                const f4 mu = *reinterpret_cast<const f4*>(bnM + 16 * t + 4 * q);
+                float d8[BT][8];
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    f4* gp = reinterpret_cast<f4*>(gzb + (bt * 16 + c) * ZS + 16 * t + 4 * q);
+                    const f4 g = *gp;
+                    const f4 zo = *reinterpret_cast<const f4*>(a.acts_aff + ((int64_t)si * a.M + mrow[bt]) * D + 16 * t + 4 * q);
+                    f4 ga, gsh, gn;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float e = expf(-Pa[bt][j] * inv) * al[j];
+                        ga[j] = -g[j] * (zo[j] - mu[j]) - glp[bt];
+                        gsh[j] = -g[j] * e;
+                        gn[j] = g[j] * e;
+                    }
+                    *gp = gn;
+                    if (live[bt]) {
+                        float* dr = a.d_aff + ((int64_t)si * a.M + mrow[bt]) * 2 * D;
+                        *reinterpret_cast<f4*>(dr + 16 * t + 4 * q) = ga;
+                        *reinterpret_cast<f4*>(dr + D + 16 * t + 4 * q) = gsh;
+                    }
+                    gather8(ga, gsh, c, q, d8[bt]);
+                }
+                pair_gh(ones, d8);
+            }
+        }
+    }
+
+    // ---- outputs: g_h (rows j = 16 jt + 4q + jj of the accumulators, column = context), g_z ----
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        if (live[bt]) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                *reinterpret_cast<f4*>(a.g_h + mrow[bt] * a.ldgh + 16 * jt + 4 * q) = gacc[bt][jt] * (inv / gsc);
+            if (a.g_z) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+                    *reinterpret_cast<f4*>(a.g_z + mrow[bt] * D + 16 * t + 4 * q) =
+                        *reinterpret_cast<const f4*>(gzb + (bt * 16 + c) * ZS + 16 * t + 4 * q) * (1.f / gsc);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Kernel 2: g_W, g_b.  blockIdx.x = job (one (coupling layer, MLP layer, net, 16-output tile) or one
+// Affine 16-feature tile), blockIdx.y = slice of the 32-context chunks.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cond_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ maxbits) {
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(g[i]));
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));
+}
+
+struct GwArgs {
+    const float* h;
+    const float* acts_c;
+    const float* d_c;
+    const float* d_aff;
+    float* g_W;   // (D_params, ldgw), zero-initialised
+    float* g_b;   // (D_params), zero-initialised
+    const unsigned* gmaxbits;
+    int64_t M, ldh, ldgw;
+    CondCfg cfg;
+};
+
+struct GwJob {
+    const float* x;   // x[m * xs + k], k < d_in   (NULL: no weight items)
+    const float* d;   // d[m * dstr + o], o < count
+    int64_t xs, dstr;
+    int64_t wbase;    // parameter index of weight (k = 0, o = 0): + k * wk + o
+    int64_t bbase;    // parameter index of bias o = 0
+    int d_in, wk, count;
+};
+
+__device__ inline GwJob gw_job(const GwArgs& a, int job) {
+    const CondCfg& c = a.cfg;
+    const int Hd = c.D / 2, U = c.U, L = c.L;
+    const int JC = 2 * (L + c.HT), JA = 2 * c.DT, JS = 2 * JC + JA;
+    const int CR = 3 * Hd + 32 * L, DR = 2 * Hd + 32 * L;
+    const int si = job / JS, stage = c.S - 1 - si;
+    int r = job % JS;
+    GwJob j;
+    const int64_t so = (int64_t)stage * c.fl.stage;
+    if (r >= 2 * JC) {  // Affine tile: gP = g_alpha / g_shift themselves
+        r -= 2 * JC;
+        const int which = r & 1, t = r >> 1;
+        j.x = nullptr;
+        j.xs = 0;
+        j.d_in = 0;
+        j.wk = 0;
+        j.wbase = 0;
+        j.d = a.d_aff + (int64_t)si * a.M * 2 * c.D + which * c.D + 16 * t;
+        j.dstr = 2 * c.D;
+        j.bbase = so + c.fl.p_up + c.fl.p_low + which * c.D + 16 * t;
+        j.count = 16;
+        return j;
+    }
+    const int low = r < JC;  // slot 2si = RealNVP(lower), 2si+1 = RealNVP(upper)
+    if (!low) r -= JC;
+    const int slot = 2 * si + (low ? 0 : 1);
+    const int64_t off = so + (low ? c.fl.p_up : 0);
+    const float* rec = a.acts_c + (int64_t)slot * a.M * CR;
+    const float* drec = a.d_c + (int64_t)slot * a.M * DR;
+    const int net = r & 1, lvl = r >> 1;
+    j.xs = CR;
+    j.dstr = DR;
+    if (lvl == 0) {
+        j.x = rec;
+        j.d_in = Hd;
+        j.wk = U;
+        j.count = U;
+        j.d = drec + 2 * Hd + net * 16;
+        j.wbase = off + (int64_t)net * Hd * U;
+        j.bbase = off + 2 * (int64_t)Hd * U + net * U;
+    } else if (lvl < L) {
+        const int64_t ol = off + 2 * (int64_t)Hd * U + 2 * U + (int64_t)(lvl - 1) * (2 * U * U + 2 * U);
+        j.x = rec + 3 * Hd + 32 * (lvl - 1) + net * 16;
+        j.d_in = U;
+        j.wk = U;
+        j.count = U;
+        j.d = drec + 2 * Hd + 32 * lvl + net * 16;
+        j.wbase = ol + (int64_t)net * U * U;
+        j.bbase = ol + 2 * (int64_t)U * U + net * U;
+    } else {
+        const int ot = lvl - L;
+        const int64_t oo = off + 2 * (int64_t)Hd * U + 2 * U + (int64_t)(L - 1) * (2 * U * U + 2 * U);
+        j.x = rec + 3 * Hd + 32 * (L - 1) + net * 16;
+        j.d_in = U;
+        j.wk = Hd;
+        j.count = 16;
+        j.d = drec + net * Hd + 16 * ot;
+        j.wbase = oo + (int64_t)net * U * Hd + 16 * ot;
+        j.bbase = oo + 2 * (int64_t)U * Hd + net * Hd + 16 * ot;
+    }
+    return j;
+}
+
+template <int DT, int KS, int NW>
+__global__ void __launch_bounds__(64 * NW)
+cond_gw_kernel(GwArgs a) {
+    constexpr int Hd = 8 * DT, JT = 2 * KS, H = 32 * KS;
+    constexpr int IPW = (Hd + 1 + NW - 1) / NW;  // items (input units + the bias) per wave
+    constexpr int CS = 36;                        // padded chunk stride (32 contexts)
+    __shared__ __attribute__((aligned(16))) float xT[(Hd + 1) * CS];
+    __shared__ __attribute__((aligned(16))) float dT[16 * CS];
+    __shared__ __attribute__((aligned(16))) float hT[H * CS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const GwJob job = gw_job(a, blockIdx.x);
+    const int items = job.d_in + 1;
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 acc[IPW][JT];
+    float gb[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        gb[i] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) acc[i][jt] = zero;
+    }
+    for (int i = tid; i < CS; i += 64 * NW) xT[job.d_in * CS + i] = 1.f;  // the bias item multiplies by one
+
+    const int64_t nchunks = (a.M + 31) / 32;
+    for (int64_t ch = blockIdx.y; ch < nchunks; ch += gridDim.y) {
+        const int64_t mbase = ch * 32;
+        __syncthreads();
+        for (int i = tid; i < 32 * job.d_in; i += 64 * NW) {
+            const int ctx = i / job.d_in, k = i - ctx * job.d_in;
+            const int64_t m = mbase + ctx;
+            xT[k * CS + ctx] = m < a.M ? job.x[m * job.xs + k] : 0.f;
+        }
+        for (int i = tid; i < 32 * 16; i += 64 * NW) {
+            const int ctx = i >> 4, o = i & 15;
+            const int64_t m = mbase + ctx;
+            dT[o * CS + ctx] = (m < a.M && o < job.count) ? job.d[m * job.dstr + o] : 0.f;
+        }
+        for (int i = tid; i < 32 * H; i += 64 * NW) {
+            const int ctx = i / H, j = i - ctx * H;
+            const int64_t m = mbase + ctx;
+            hT[j * CS + ctx] = m < a.M ? a.h[m * a.ldh + j] : 0.f;
+        }
+        __syncthreads();
+        h8 Bh[JT], Bl[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+            csplit8(*reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + 8 * q),
+                    *reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + 8 * q + 4), Bh[jt], Bl[jt]);
+        const f4 d0 = *reinterpret_cast<const f4*>(dT + r * CS + 8 * q);
+        const f4 d1 = *reinterpret_cast<const f4*>(dT + r * CS + 8 * q + 4);
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int k = wave + i * NW;
+            if (k < items) {  // wave-uniform
+                const f4 a0 = *reinterpret_cast<const f4*>(xT + k * CS + 8 * q) * d0;
+                const f4 a1 = *reinterpret_cast<const f4*>(xT + k * CS + 8 * q + 4) * d1;
+                gb[i] += (a0[0] + a0[1]) + (a0[2] + a0[3]) + (a1[0] + a1[1]) + (a1[2] + a1[3]);
+                h8 ah, al;
+                csplit8(a0, a1, ah, al);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    acc[i][jt] = cmfma32h(ah, Bh[jt], acc[i][jt]);
+                    acc[i][jt] = cmfma32h(al, Bh[jt], acc[i][jt]);
+                    acc[i][jt] = cmfma32h(ah, Bl[jt], acc[i][jt]);
+                }
+            }
+        }
+    }
+    const float ig = 1.f / cond_gscale(*a.gmaxbits);  // the deltas were computed on scaled upstream gradients
+    // ---- merge: rows of the accumulators = outputs 4q + jj, columns = hidden unit 16 jt + r ----
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int k = wave + i * NW;
+        if (k < items) {
+            const int64_t pb = k < job.d_in ? job.wbase + (int64_t)k * job.wk : job.bbase;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int o = 4 * q + jj;
+                if (o < job.count) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) atomicAdd(a.g_W + (pb + o) * a.ldgw + 16 * jt + r, acc[i][jt][jj] * ig);
+                }
+            }
+            const float s = reduce_q(gb[i]);
+            if (q == 0 && r < job.count) atomicAdd(a.g_b + pb + r, s * ig);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+int64_t cond_acts_floats(int64_t M, int D, int S, int L) { return (int64_t)S * M * D + 2 * (int64_t)S * M * (3 * (D / 2) + 32 * L); }
+int64_t cond_deltas_floats(int64_t M, int D, int S, int L) { return 2 * (int64_t)S * M * D + 2 * (int64_t)S * M * (D + 32 * L); }
+
+int64_t cond_flow_bwd_workspace(int D, int S, int L, int U, int H) {
+    const CondCfg c = cond_cfg(D, S, L, U, H);
+    const int KS = H / 32;
+    return 256 + c.T * (int64_t)(KS * 128 + 4) * 16 + (c.T / 2) * (int64_t)(KS * 256) * 16;
+}
+
+template <int DT, int KS, int BT, int NW>
+static int launch_bwd_variant(const CondBwdArgs& a, hipStream_t st) {
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> PStream;
+    typedef TileStream<KS * 256, 4 / KS, 64 * NW> TStream;
+    constexpr int D = 16 * DT;
+    const size_t smem = (size_t)2 * (PStream::CHUNK_U4 + TStream::CHUNK_U4) * 16 + (size_t)NW * 16 * BT * (D + 4) * 4;
+    auto k = cond_flow_bwd_kernel<DT, KS, BT, NW>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const int64_t per_wg = (int64_t)NW * 16 * BT;
+    const int64_t blocks = (a.M + per_wg - 1) / per_wg;
+    if (blocks > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "cond_flow_bwd: grid too large");
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a);
+    return check_launch("cond_flow_bwd");
+}
+
+template <int DT, int KS>
+static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) {
+    int v = g_cond_variant;
+    if (v == 0) v = a.M >= 256 * 128 ? 3 : 1;
+    int rc = v >= 2 ? launch_bwd_variant<DT, KS, 2, 8>(a, st) : launch_bwd_variant<DT, KS, 1, 4>(a, st);
+    if (rc) return rc;
+    const CondCfg& c = g.cfg;
+    const int jobs = c.S * (2 * 2 * (c.L + c.HT) + 2 * c.DT);
+    const int64_t nchunks = (a.M + 31) / 32;
+    int64_t split = 2048 / jobs;
+    if (split < 1) split = 1;
+    if (split > nchunks) split = nchunks;
+    hipLaunchKernelGGL((cond_gw_kernel<DT, KS, 8>), dim3((unsigned)jobs, (unsigned)split), dim3(512), 0, st, g);
+    return check_launch("cond_gw");
+}
+
+int launch_cond_flow_backward(const float* g_lp, const float* h, const float* W, const float* b, const float* bn_mean,
+                              const float* bn_alpha, const float* acts, float* deltas, float* g_h, float* g_W,
+                              float* g_b, float* g_z, int64_t M, int D, int S, int L, int U, int H, int64_t ldh,
+                              int64_t ldw, int64_t ldgh, int64_t ldgw, void* ws, hipStream_t st) {
+    const CondCfg cfg = cond_cfg(D, S, L, U, H);
+    const int KS = H / 32;
+    char* base = reinterpret_cast<char*>(ws);
+    u4* pimg = reinterpret_cast<u4*>(base + 256);
+    u4* timg = pimg + cfg.T * (int64_t)(KS * 128 + 4);
+    int rc = launch_cond_image(W, b, ldw, cfg, ws, pimg, 1, st);
+    if (rc) return rc;
+    const unsigned* maxbits = reinterpret_cast<const unsigned*>(ws);
+    const unsigned tb = (unsigned)((cfg.T / 2 + 3) / 4);
+    if (KS == 1) hipLaunchKernelGGL(cond_timage_kernel<1>, dim3(tb), dim3(256), 0, st, W, ldw, cfg, maxbits, timg);
+    else if (KS == 2) hipLaunchKernelGGL(cond_timage_kernel<2>, dim3(tb), dim3(256), 0, st, W, ldw, cfg, maxbits, timg);
+    else hipLaunchKernelGGL(cond_timage_kernel<4>, dim3(tb), dim3(256), 0, st, W, ldw, cfg, maxbits, timg);
+    unsigned* gmax = reinterpret_cast<unsigned*>(ws) + 2;
+    if (hipMemsetAsync(gmax, 0, 4, st) != hipSuccess) return fail(TNF_ELAUNCH, "cond_flow_bwd: memset failed");
+    hipLaunchKernelGGL(cond_gmax_kernel, dim3(64), dim3(256), 0, st, g_lp, M, gmax);
+    rc = check_launch("cond_flow_bwd_prep");
+    if (rc) return rc;
+    if (hipMemsetAsync(g_W, 0, (size_t)cfg.fl.total * ldgw * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(g_b, 0, (size_t)cfg.fl.total * sizeof(float), st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "cond_flow_bwd: memset failed");
+    CondBwdArgs a;
+    a.g_lp = g_lp; a.gmaxbits = gmax; a.h = h; a.pimg = pimg; a.timg = timg; a.inv_scale = reinterpret_cast<const float*>(ws) + 1;
+    a.bn_mean = bn_mean; a.bn_alpha = bn_alpha;
+    a.acts_aff = acts; a.acts_c = acts + (int64_t)S * M * D;
+    a.d_aff = deltas; a.d_c = deltas + 2 * (int64_t)S * M * D;
+    a.g_h = g_h; a.g_z = g_z; a.M = M; a.ldh = ldh; a.ldgh = ldgh; a.T = cfg.T; a.S = S; a.L = L; a.U = U;
+    GwArgs g;
+    g.h = h; g.acts_c = a.acts_c; g.d_c = a.d_c; g.d_aff = a.d_aff; g.g_W = g_W; g.g_b = g_b;
+    g.M = M; g.ldh = ldh; g.ldgw = ldgw; g.cfg = cfg; g.gmaxbits = gmax;
+    if (D == 64) {
+        if (KS == 1) return launch_bwd_dk<4, 1>(a, g, st);
+        if (KS == 2) return launch_bwd_dk<4, 2>(a, g, st);
+        return launch_bwd_dk<4, 4>(a, g, st);
+    }
+    if (KS == 1) return launch_bwd_dk<2, 1>(a, g, st);
+    if (KS == 2) return launch_bwd_dk<2, 2>(a, g, st);
+    return launch_bwd_dk<2, 4>(a, g, st);
+}
+
+}  // namespace tnf

@@ -175,8 +175,16 @@ int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld,
 bool cond_flow_supported(int D, int S, int L, int U, int H);
 int64_t cond_flow_workspace(int D, int S, int L, int U, int H);
 int launch_cond_flow_log_prob(const float* z, const float* h, const float* W, const float* b, const float* bn_mean,
-                              const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, int64_t M, int D,
-                              int S, int L, int U, int H, int64_t ldh, int64_t ldw, void* ws, hipStream_t st);
+                              const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, float* acts,
+                              int64_t M, int D, int S, int L, int U, int H, int64_t ldh, int64_t ldw, void* ws,
+                              hipStream_t st);
+int64_t cond_acts_floats(int64_t M, int D, int S, int L);
+int64_t cond_deltas_floats(int64_t M, int D, int S, int L);
+int64_t cond_flow_bwd_workspace(int D, int S, int L, int U, int H);
+int launch_cond_flow_backward(const float* g_lp, const float* h, const float* W, const float* b, const float* bn_mean,
+                              const float* bn_alpha, const float* acts, float* deltas, float* g_h, float* g_W,
+                              float* g_b, float* g_z, int64_t M, int D, int S, int L, int U, int H, int64_t ldh,
+                              int64_t ldw, int64_t ldgh, int64_t ldgw, void* ws, hipStream_t st);
 int launch_to_interval(int dtype, const void* z, const float* consts, void* z_out, void* log_det, int64_t rows, int D,
                        int inverse, hipStream_t st);
 int launch_to_interval_backward(int dtype, const void* z, const float* consts, const void* g_zout, const void* g_ld,

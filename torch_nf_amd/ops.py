@@ -628,3 +628,63 @@ def cond_flow_log_prob_raw(z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U, wa
                                              sld.data_ptr() if want_sld else None, M, D, S, L, U, Hp,
                                              hc.stride(0), wc.stride(0), ws.data_ptr(), nbytes, _lib.stream_ptr()))
     return lp, z0, sld
+
+
+class _CondFlowLogProbFn(torch.autograd.Function):
+    """Training pair of the fused conditioner + flow: tnf_cond_flow_log_prob_fwd_f32 keeps per-layer
+    activations (6 KB per context at D = 64), tnf_cond_flow_log_prob_bwd_f32 returns the gradients of
+    param_net's last Linear and of its input; torch autograd carries on through the rest of param_net."""
+
+    @staticmethod
+    def forward(ctx, z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U):
+        dev = _lib.require_device()
+        M, H = h.shape
+        Hp = _cond_width(H)
+        zc = _stage(z.detach().float(), dev)
+        hc = _pad_cols(_stage(h, dev), Hp)
+        wc = _pad_cols(_stage(weight, dev), Hp)
+        bc = _stage(bias.detach().float(), dev)
+        mean, alpha = _stats(bn_mean, dev), _stats(bn_alpha, dev)
+        lp = torch.empty((M,), dtype=torch.float32, device=dev)
+        acts = torch.empty((max(1, check(lib.tnf_cond_flow_acts_floats(M, D, S, L))),), dtype=torch.float32, device=dev)
+        nbytes = check(lib.tnf_cond_flow_workspace_bytes(D, S, L, U, Hp))
+        ws = _workspace(nbytes, dev)
+        if M > 0:
+            check(lib.tnf_cond_flow_log_prob_fwd_f32(zc.data_ptr(), hc.data_ptr(), wc.data_ptr(), bc.data_ptr(),
+                                                     mean.data_ptr(), alpha.data_ptr(), lp.data_ptr(),
+                                                     acts.data_ptr(), M, D, S, L, U, Hp, hc.stride(0), wc.stride(0),
+                                                     ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        ctx.save_for_backward(hc, wc, bc, mean, alpha, acts)
+        ctx.cfg = (M, H, Hp, D, S, L, U)
+        ctx.homes = (z.device, h.device, weight.device, bias.device)
+        return lp
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        hc, wc, bc, mean, alpha, acts = ctx.saved_tensors
+        M, H, Hp, D, S, L, U = ctx.cfg
+        dev = hc.device
+        P = wc.shape[0]
+        need_z = ctx.needs_input_grad[0]
+        g = _stage(g_lp.detach().float(), dev)
+        g_h = torch.zeros((M, Hp), dtype=torch.float32, device=dev)
+        g_w = torch.empty((P, Hp), dtype=torch.float32, device=dev)
+        g_b = torch.empty((P,), dtype=torch.float32, device=dev)
+        g_z = torch.zeros((M, D), dtype=torch.float32, device=dev) if need_z else None
+        deltas = torch.empty((max(1, check(lib.tnf_cond_flow_deltas_floats(M, D, S, L))),), dtype=torch.float32,
+                             device=dev)
+        nbytes = check(lib.tnf_cond_flow_bwd_workspace_bytes(D, S, L, U, Hp))
+        ws = _workspace(nbytes, dev)
+        check(lib.tnf_cond_flow_log_prob_bwd_f32(g.data_ptr(), hc.data_ptr(), wc.data_ptr(), bc.data_ptr(),
+                                                 mean.data_ptr(), alpha.data_ptr(), acts.data_ptr(),
+                                                 deltas.data_ptr(), g_h.data_ptr(), g_w.data_ptr(), g_b.data_ptr(),
+                                                 g_z.data_ptr() if need_z else None, M, D, S, L, U, Hp,
+                                                 hc.stride(0), wc.stride(0), g_h.stride(0), g_w.stride(0),
+                                                 ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        hz, hh, hw, hb = ctx.homes
+        out_z = g_z.to(hz) if need_z else None
+        return (out_z, g_h[:, :H].to(hh), g_w[:, :H].to(hw), g_b.to(hb), None, None, None, None, None, None)
+
+
+def cond_flow_log_prob_train(z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U):
+    return _CondFlowLogProbFn.apply(z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U)
