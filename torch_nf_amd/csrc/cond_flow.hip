@@ -106,12 +106,12 @@ __global__ void __launch_bounds__(64 * NW)
 cond_flow_kernel(CondArgs a) {
     constexpr int D = 16 * DT, Hd = D / 2, HT = DT / 2;
     constexpr int ZS = D + 4, HS = 20, CT = 16 * BT;
-    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> Stream;
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, NW, kCondNS<KS, BT, NW>> Stream;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u4* stage = reinterpret_cast<u4*>(smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    float* wl = reinterpret_cast<float*>(stage + 2 * Stream::CHUNK_U4) + wave * (CT * (ZS + 2 * HS));
+    float* wl = reinterpret_cast<float*>(stage + Stream::LDS_U4) + wave * (CT * (ZS + 2 * HS));
     float* zb = wl;                 // [CT][ZS]  the contexts' running state
     float* hbt = wl + CT * ZS;      // [CT][HS]  hidden activations of the t net
     float* hbs = hbt + CT * HS;     // [CT][HS]  ... of the s net
@@ -138,8 +138,8 @@ cond_flow_kernel(CondArgs a) {
                     *reinterpret_cast<const f4*>(hr + 32 * ks + 8 * q + 4), bh[bt][ks], bl[bt][ks]);
     }
     const float inv = *a.inv_scale;
-    Stream ts;
-    ts.init(a.image, stage, a.T);
+    TilePipe<KS, BT, Stream> pipe;
+    pipe.init(a.image, stage, a.T, lane);
 
     float ld[BT];
 #pragma unroll
@@ -158,18 +158,35 @@ cond_flow_kernel(CondArgs a) {
         f4 at[BT], as[BT], Pt[BT], Ps[BT];
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) at[bt] = as[bt] = zero;
+        // Software pipeline: the FMAs that consume a tile's result are placed in the shadow of the NEXT
+        // tile's MFMAs (t results under the s tile's, s results under the next t tile's) -- with two waves
+        // per SIMD in barrier lock-step there is nobody else to fill the matrix pipe meanwhile.
+        float xp[BT];  // scaled input of the pending s-net tile
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            xp[bt] = 0.f;
+            Ps[bt] = zero;
+        }
         for (int k = 0; k < Hd; ++k) {
-            tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Pt);
-            tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Ps);
+            float x[BT];
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) x[bt] = zb[(bt * 16 + c) * ZS + cond_off + k] * inv;
+            pipe.gemm0(lane, bh, bl, Pt);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) as[bt] += xp[bt] * Ps[bt];
+            pipe.gemm1(lane, bh, bl, Ps);
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) {
-                const float x = zb[(bt * 16 + c) * ZS + cond_off + k] * inv;
-                at[bt] += x * Pt[bt];
-                as[bt] += x * Ps[bt];
+                at[bt] += x[bt] * Pt[bt];
+                xp[bt] = x[bt];
             }
+            pipe.refill1(lane);
         }
-        tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Pt);
-        tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Ps);
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) as[bt] += xp[bt] * Ps[bt];
+        pipe.gemm0(lane, bh, bl, Pt);
+        pipe.gemm1(lane, bh, bl, Ps);
+        pipe.refill1(lane);
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) {
             at[bt] += inv * Pt[bt];
@@ -177,8 +194,8 @@ cond_flow_kernel(CondArgs a) {
             f4 ht4, hs4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ht4[j] = tanhf(at[bt][j]);
-                hs4[j] = tanhf(as[bt][j]);
+                ht4[j] = fast_tanh(at[bt][j]);
+                hs4[j] = fast_tanh(as[bt][j]);
             }
             *reinterpret_cast<f4*>(hbt + (bt * 16 + c) * HS + 4 * q) = ht4;
             *reinterpret_cast<f4*>(hbs + (bt * 16 + c) * HS + 4 * q) = hs4;
@@ -195,17 +212,34 @@ cond_flow_kernel(CondArgs a) {
         for (int l = 1; l < a.L; ++l) {
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) at[bt] = as[bt] = zero;
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                xp[bt] = 0.f;
+                Ps[bt] = zero;
+            }
             for (int k = 0; k < U; ++k) {
-                tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Pt);
-                tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Ps);
+                float xt[BT], xs[BT];
 #pragma unroll
                 for (int bt = 0; bt < BT; ++bt) {
-                    at[bt] += (hbt[(bt * 16 + c) * HS + k] * inv) * Pt[bt];
-                    as[bt] += (hbs[(bt * 16 + c) * HS + k] * inv) * Ps[bt];
+                    xt[bt] = hbt[(bt * 16 + c) * HS + k] * inv;
+                    xs[bt] = hbs[(bt * 16 + c) * HS + k] * inv;
                 }
+                pipe.gemm0(lane, bh, bl, Pt);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) as[bt] += xp[bt] * Ps[bt];
+                pipe.gemm1(lane, bh, bl, Ps);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    at[bt] += xt[bt] * Pt[bt];
+                    xp[bt] = xs[bt];
+                }
+                pipe.refill1(lane);
             }
-            tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Pt);
-            tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Ps);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) as[bt] += xp[bt] * Ps[bt];
+            pipe.gemm0(lane, bh, bl, Pt);
+            pipe.gemm1(lane, bh, bl, Ps);
+            pipe.refill1(lane);
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) {
                 at[bt] += inv * Pt[bt];
@@ -213,8 +247,8 @@ cond_flow_kernel(CondArgs a) {
                 f4 ht4, hs4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    ht4[j] = tanhf(at[bt][j]);
-                    hs4[j] = tanhf(as[bt][j]);
+                    ht4[j] = fast_tanh(at[bt][j]);
+                    hs4[j] = fast_tanh(as[bt][j]);
                 }
                 *reinterpret_cast<f4*>(hbt + (bt * 16 + c) * HS + 4 * q) = ht4;
                 *reinterpret_cast<f4*>(hbs + (bt * 16 + c) * HS + 4 * q) = hs4;
@@ -230,6 +264,11 @@ cond_flow_kernel(CondArgs a) {
         for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
             for (int o = 0; o < HT; ++o) ot[bt][o] = os[bt][o] = zero;
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            xp[bt] = 0.f;
+            Ps[bt] = zero;
+        }
         for (int k = 0; k < U; ++k) {
             float xt[BT], xs[BT];
 #pragma unroll
@@ -239,19 +278,29 @@ cond_flow_kernel(CondArgs a) {
             }
 #pragma unroll
             for (int o = 0; o < HT; ++o) {
-                tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Pt);
-                tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Ps);
+                pipe.gemm0(lane, bh, bl, Pt);
+                if (o > 0) {
 #pragma unroll
-                for (int bt = 0; bt < BT; ++bt) {
-                    ot[bt][o] += xt[bt] * Pt[bt];
-                    os[bt][o] += xs[bt] * Ps[bt];
+                    for (int bt = 0; bt < BT; ++bt) os[bt][o - 1] += xs[bt] * Ps[bt];
+                } else {
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) os[bt][HT - 1] += xp[bt] * Ps[bt];  // previous k's last s tile
                 }
+                pipe.gemm1(lane, bh, bl, Ps);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) ot[bt][o] += xt[bt] * Pt[bt];
+                pipe.refill1(lane);
             }
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) xp[bt] = xs[bt];
         }
 #pragma unroll
+        for (int bt = 0; bt < BT; ++bt) os[bt][HT - 1] += xp[bt] * Ps[bt];
+#pragma unroll
         for (int o = 0; o < HT; ++o) {
-            tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Pt);
-            tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Ps);
+            pipe.gemm0(lane, bh, bl, Pt);
+            pipe.gemm1(lane, bh, bl, Ps);
+            pipe.refill1(lane);
 #pragma unroll
             for (int bt = 0; bt < BT; ++bt) {
                 const f4 t4 = ot[bt][o] + inv * Pt[bt];
@@ -260,7 +309,7 @@ cond_flow_kernel(CondArgs a) {
                 f4 zv = *zp;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    zv[j] = (zv[j] - t4[j]) * expf(-s4[j]);
+                    zv[j] = (zv[j] - t4[j]) * fast_exp(-s4[j]);
                     ld[bt] += s4[j];
                 }
                 *zp = zv;
@@ -281,13 +330,14 @@ cond_flow_kernel(CondArgs a) {
             f4 Pa[BT], Psh[BT];
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
-                tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Pa);
-                tile_gemm<KS, BT>(ts.next(), lane, bh, bl, Psh);
+                pipe.gemm0(lane, bh, bl, Pa);
+                pipe.gemm1(lane, bh, bl, Psh);
+                pipe.refill1(lane);
                 const f4 al = *reinterpret_cast<const f4*>(bnA + 16 * t + 4 * q);
                 const f4 mu = *reinterpret_cast<const f4*>(bnM + 16 * t + 4 * q);
                 float lal = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lal += logf(al[j]);
+                for (int j = 0; j < 4; ++j) lal += fast_log(al[j]);
 #pragma unroll
                 for (int bt = 0; bt < BT; ++bt) {
                     f4* zp = reinterpret_cast<f4*>(zb + (bt * 16 + c) * ZS + 16 * t + 4 * q);
@@ -295,7 +345,7 @@ cond_flow_kernel(CondArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float aa = Pa[bt][j] * inv, sh = Psh[bt][j] * inv;
-                        zv[j] = (zv[j] - sh) * expf(-aa) * al[j] + mu[j];
+                        zv[j] = (zv[j] - sh) * fast_exp(-aa) * al[j] + mu[j];
                         ld[bt] += aa;
                     }
                     ld[bt] -= lal;
@@ -315,7 +365,7 @@ cond_flow_kernel(CondArgs a) {
                 const f4 mu = *reinterpret_cast<const f4*>(bnM + 16 * t + 4 * q);
                 float lal = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lal += logf(al[j]);
+                for (int j = 0; j < 4; ++j) lal += fast_log(al[j]);
 #pragma unroll
                 for (int bt = 0; bt < BT; ++bt) {
                     f4* zp = reinterpret_cast<f4*>(zb + (bt * 16 + c) * ZS + 16 * t + 4 * q);
@@ -370,9 +420,9 @@ int64_t cond_flow_workspace(int D, int S, int L, int U, int H) {
 
 template <int DT, int KS, int BT, int NW, bool SAVE>
 static int launch_cond_variant(const CondArgs& a, hipStream_t st) {
-    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> Stream;
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, NW, kCondNS<KS, BT, NW>> Stream;
     constexpr int D = 16 * DT;
-    const size_t smem = (size_t)2 * Stream::CHUNK_U4 * 16 + (size_t)NW * 16 * BT * (D + 4 + 40) * 4;
+    const size_t smem = (size_t)Stream::LDS_U4 * 16 + (size_t)NW * 16 * BT * (D + 4 + 40) * 4;
     auto k = cond_flow_kernel<DT, KS, BT, NW, SAVE>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -389,10 +439,12 @@ template <int DT, int KS>
 static int launch_cond_dk(const CondArgs& a, hipStream_t st) {
     int v = g_cond_variant;
     if (v == 0) v = a.M >= 256 * 256 ? 3 : (a.M >= 256 * 128 ? 2 : 1);
-    if (a.acts_c) {  // training forward: two shapes only (compile time)
+    if (a.acts_c) {  // training forward: fewer shapes (compile time)
+        if (v == 4) return launch_cond_variant<DT, KS, 4, 4, true>(a, st);
         if (v >= 2) return launch_cond_variant<DT, KS, 2, 8, true>(a, st);
         return launch_cond_variant<DT, KS, 1, 4, true>(a, st);
     }
+    if (v == 4) return launch_cond_variant<DT, KS, 4, 4, false>(a, st);
     if (v == 3) return launch_cond_variant<DT, KS, 2, 8, false>(a, st);
     if (v == 2) return launch_cond_variant<DT, KS, 1, 8, false>(a, st);
     return launch_cond_variant<DT, KS, 1, 4, false>(a, st);

@@ -99,19 +99,27 @@ __device__ __forceinline__ void gather8(f4 vt, f4 vs, int c, int q, float (&out)
     }
 }
 
+// element k (wave-uniform, 0..15) of context c's 16-vector held 4 per q-lane: no memory traffic inside the
+// k loops (a global load there would make hipcc wait vmcnt(0), i.e. for the LDS-DMA copies in flight)
+__device__ __forceinline__ float bcast16(f4 v, int k, int c) {
+    const int j = k & 3;
+    const float sel = j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
+    return __shfl(sel, c + 16 * (k >> 2));
+}
+
 template <int DT, int KS, int BT, int NW>
 __global__ void __launch_bounds__(64 * NW)
 cond_flow_bwd_kernel(CondBwdArgs a) {
     constexpr int D = 16 * DT, Hd = D / 2, HT = DT / 2, JT = 2 * KS;
     constexpr int ZS = D + 4, CT = 16 * BT;
-    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> PStream;
-    typedef TileStream<KS * 256, 4 / KS, 64 * NW> TStream;
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, NW, 2> PStream;
+    typedef TileStream<KS * 256, 4 / KS, NW, 2> TStream;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u4* pstage = reinterpret_cast<u4*>(smem_raw);
-    u4* tstage = pstage + 2 * PStream::CHUNK_U4;
+    u4* tstage = pstage + PStream::LDS_U4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    float* gzb = reinterpret_cast<float*>(tstage + 2 * TStream::CHUNK_U4) + wave * (CT * ZS);  // [CT][ZS] g_z
+    float* gzb = reinterpret_cast<float*>(tstage + TStream::LDS_U4) + wave * (CT * ZS);  // [CT][ZS] g_z
 
     const int64_t m0 = ((int64_t)blockIdx.x * NW + wave) * CT;
     const int CR = 3 * Hd + 32 * a.L, DR = 2 * Hd + 32 * a.L;
@@ -146,9 +154,9 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
         }
     }
     const float inv = *a.inv_scale;
-    PStream ps;
+    TilePipe<KS, BT, PStream> pipe;
     TStream tq;
-    ps.init(a.pimg, pstage, a.T);
+    pipe.init(a.pimg, pstage, a.T, lane);
     tq.init(a.timg, tstage, a.T / 2);
 
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -206,7 +214,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                 f4 gn, vt, vs;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float e = expf(-s4[j]);
+                    const float e = fast_exp(-s4[j]);
                     vt[j] = -e * g[j];
                     vs[j] = -x2[j] * g[j] - glp[bt];
                     gn[j] = e * g[j];
@@ -226,19 +234,26 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
         for (int bt = 0; bt < BT; ++bt) dht[bt] = dhs[bt] = zero;
         {
             const int aoff = 3 * Hd + 32 * (a.L - 1);
+            f4 hat[BT], has[BT];  // the layer's inputs: hidden activations, 4 per lane
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                hat[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 4 * q);
+                has[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 16 + 4 * q);
+            }
             for (int k = 0; k < U; ++k) {
                 float xt[BT], xs[BT], xsel[BT], pt[BT], pss[BT];
 #pragma unroll
                 for (int bt = 0; bt < BT; ++bt) {
-                    xt[bt] = rec[bt][aoff + k];
-                    xs[bt] = rec[bt][aoff + 16 + k];
+                    xt[bt] = bcast16(hat[bt], k, c);
+                    xs[bt] = bcast16(has[bt], k, c);
                     xsel[bt] = q < 2 ? xt[bt] : xs[bt];
                     pt[bt] = pss[bt] = 0.f;
                 }
 #pragma unroll
                 for (int o = 0; o < HT; ++o) {
-                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pt);
-                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Ps);
+                    pipe.gemm0(lane, bh, bl, Pt);
+                    pipe.gemm1(lane, bh, bl, Ps);
+                    pipe.refill1(lane);
 #pragma unroll
                     for (int bt = 0; bt < BT; ++bt) {
                         pt[bt] += dot4(Pt[bt], dt[o][bt]);
@@ -260,8 +275,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
             }
 #pragma unroll
             for (int o = 0; o < HT; ++o) {  // output-layer biases: gP = delta
-                ps.next();
-                ps.next();
+                pipe.skip_pair(lane);
                 pair_gh(ones, d8o[o]);
             }
         }
@@ -281,16 +295,23 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
 #pragma unroll
                 for (int bt = 0; bt < BT; ++bt) nt[bt] = ns[bt] = zero;
                 const int aoff = 3 * Hd + 32 * (l - 1);
+                f4 hat[BT], has[BT];
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    hat[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 4 * q);
+                    has[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 16 + 4 * q);
+                }
                 for (int k = 0; k < U; ++k) {
                     float xt[BT], xs[BT], xsel[BT];
 #pragma unroll
                     for (int bt = 0; bt < BT; ++bt) {
-                        xt[bt] = rec[bt][aoff + k];
-                        xs[bt] = rec[bt][aoff + 16 + k];
+                        xt[bt] = bcast16(hat[bt], k, c);
+                        xs[bt] = bcast16(has[bt], k, c);
                         xsel[bt] = q < 2 ? xt[bt] : xs[bt];
                     }
-                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pt);
-                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Ps);
+                    pipe.gemm0(lane, bh, bl, Pt);
+                    pipe.gemm1(lane, bh, bl, Ps);
+                    pipe.refill1(lane);
                     pair_gh(xsel, d8);
 #pragma unroll
                     for (int bt = 0; bt < BT; ++bt) {
@@ -304,8 +325,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                         }
                     }
                 }
-                ps.next();
-                ps.next();
+                pipe.skip_pair(lane);
                 pair_gh(ones, d8);
 #pragma unroll
                 for (int bt = 0; bt < BT; ++bt) {
@@ -313,12 +333,23 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                     dhs[bt] = ns[bt];
                 }
             } else {
+                f4 x1v[BT][HT];  // x1, the layer's conditioning half: the same input for both nets
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+                    for (int t = 0; t < HT; ++t) x1v[bt][t] = *reinterpret_cast<const f4*>(rec[bt] + 16 * t + 4 * q);
                 for (int k = 0; k < Hd; ++k) {
                     float x[BT];
 #pragma unroll
-                    for (int bt = 0; bt < BT; ++bt) x[bt] = rec[bt][k];  // x1: the same input for both nets
-                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pt);
-                    tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Ps);
+                    for (int bt = 0; bt < BT; ++bt) {
+                        f4 v = x1v[bt][0];
+#pragma unroll
+                        for (int t = 1; t < HT; ++t) v = (k >> 4) == t ? x1v[bt][t] : v;
+                        x[bt] = bcast16(v, k & 15, c);
+                    }
+                    pipe.gemm0(lane, bh, bl, Pt);
+                    pipe.gemm1(lane, bh, bl, Ps);
+                    pipe.refill1(lane);
                     pair_gh(x, d8);
 #pragma unroll
                     for (int bt = 0; bt < BT; ++bt) {
@@ -326,8 +357,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                         if (q == 0) gzb[(bt * 16 + c) * ZS + cond_off + k] += g;
                     }
                 }
-                ps.next();
-                ps.next();
+                pipe.skip_pair(lane);
                 pair_gh(ones, d8);
             }
         }
@@ -355,8 +385,8 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
             f4 Pa[BT];
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
-                tile_gemm<KS, BT>(ps.next(), lane, bh, bl, Pa);
-                ps.next();  // the shift tile: its values are not needed backwards
+                pipe.gemm0(lane, bh, bl, Pa);
+                pipe.skip1(lane);  // the shift tile: its values are not needed backwards
                 const f4 al = *reinterpret_cast<const f4*>(bnA + 16 * t + 4 * q);
                 const f4 mu = *reinterpret_cast<const f4*>(bnM + 16 * t + 4 * q);
                 float d8[BT][8];
@@ -368,7 +398,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                     f4 ga, gsh, gn;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float e = expf(-Pa[bt][j] * inv) * al[j];
+                        const float e = fast_exp(-Pa[bt][j] * inv) * al[j];
                         ga[j] = -g[j] * (zo[j] - mu[j]) - glp[bt];
                         gsh[j] = -g[j] * e;
                         gn[j] = g[j] * e;
@@ -501,9 +531,12 @@ __device__ inline GwJob gw_job(const GwArgs& a, int job) {
 template <int DT, int KS, int NW>
 __global__ void __launch_bounds__(64 * NW)
 cond_gw_kernel(GwArgs a) {
-    constexpr int Hd = 8 * DT, JT = 2 * KS, H = 32 * KS;
+    constexpr int Hd = 8 * DT, JT = 2 * KS, H = 32 * KS, NT = 64 * NW;
     constexpr int IPW = (Hd + 1 + NW - 1) / NW;  // items (input units + the bias) per wave
-    constexpr int CS = 36;                        // padded chunk stride (32 contexts)
+    constexpr int CH = KS == 4 ? 64 : 128;        // contexts staged per step
+    constexpr int CS = CH + 4;                    // padded row stride of the transposed staging buffers
+    constexpr int XQ = Hd / 4;                    // float4 per context row, at most
+    constexpr int NX = (CH * XQ + NT - 1) / NT, ND = (CH * 4 + NT - 1) / NT, NH = (CH * (H / 4) + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float xT[(Hd + 1) * CS];
     __shared__ __attribute__((aligned(16))) float dT[16 * CS];
     __shared__ __attribute__((aligned(16))) float hT[H * CS];
@@ -511,6 +544,7 @@ cond_gw_kernel(GwArgs a) {
     const int r = lane & 15, q = lane >> 4;
     const GwJob job = gw_job(a, blockIdx.x);
     const int items = job.d_in + 1;
+    const int xq = (job.d_in + 3) >> 2;  // float4 per context row of x actually read (rows are padded to 4)
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     f4 acc[IPW][JT];
     float gb[IPW];
@@ -520,49 +554,114 @@ cond_gw_kernel(GwArgs a) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) acc[i][jt] = zero;
     }
-    for (int i = tid; i < CS; i += 64 * NW) xT[job.d_in * CS + i] = 1.f;  // the bias item multiplies by one
+    for (int i = tid; i < CS; i += NT) xT[job.d_in * CS + i] = 1.f;  // the bias item multiplies by one
 
-    const int64_t nchunks = (a.M + 31) / 32;
-    for (int64_t ch = blockIdx.y; ch < nchunks; ch += gridDim.y) {
-        const int64_t mbase = ch * 32;
+    // register-staged prefetch of one step: x rows, delta rows, h rows of CH contexts (zero past M)
+    f4 px[NX], pd[ND], ph[NH];
+    auto fetch = [&](int64_t mbase) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * NT;
+            const int ctx = xq ? idx / xq : 0, k4 = xq ? idx - ctx * xq : 0;
+            const int64_t m = mbase + ctx;
+            const bool ok = xq && ctx < CH && m < a.M;
+            const f4 v = *reinterpret_cast<const f4*>((ok ? job.x + m * job.xs + 4 * k4 : a.h));
+            px[i] = ok ? v : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * NT;
+            const int ctx = idx >> 2, o4 = idx & 3;
+            const int64_t m = mbase + ctx;
+            const bool ok = ctx < CH && m < a.M;
+            const f4 v = *reinterpret_cast<const f4*>(job.d + (ok ? m : 0) * job.dstr + 4 * o4);
+            pd[i] = ok ? v : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int idx = tid + i * NT;
+            const int ctx = idx / (H / 4), j4 = idx - ctx * (H / 4);
+            const int64_t m = mbase + ctx;
+            const bool ok = ctx < CH && m < a.M;
+            const f4 v = *reinterpret_cast<const f4*>(a.h + (ok ? m : 0) * a.ldh + 4 * j4);
+            ph[i] = ok ? v : zero;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * NT;
+            const int ctx = xq ? idx / xq : 0, k4 = xq ? idx - ctx * xq : 0;
+            if (xq && ctx < CH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * k4 + e < job.d_in) xT[(4 * k4 + e) * CS + ctx] = px[i][e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * NT;
+            const int ctx = idx >> 2, o4 = idx & 3;
+            if (ctx < CH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dT[(4 * o4 + e) * CS + ctx] = (4 * o4 + e < job.count) ? pd[i][e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int idx = tid + i * NT;
+            const int ctx = idx / (H / 4), j4 = idx - ctx * (H / 4);
+            if (ctx < CH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hT[(4 * j4 + e) * CS + ctx] = ph[i][e];
+            }
+        }
+    };
+
+    const int64_t nsteps = (a.M + CH - 1) / CH;
+    int64_t st = blockIdx.y;
+    if (st < nsteps) fetch(st * CH);
+    for (; st < nsteps; st += gridDim.y) {
+#if TNF_COND_ABLATE == 3  // timing experiment: stage only the first step
+        if (st == (int64_t)blockIdx.y) {
+            commit();
+            __syncthreads();
+        }
+#else
+        __syncthreads();  // everyone is done reading the previous step
+        commit();
         __syncthreads();
-        for (int i = tid; i < 32 * job.d_in; i += 64 * NW) {
-            const int ctx = i / job.d_in, k = i - ctx * job.d_in;
-            const int64_t m = mbase + ctx;
-            xT[k * CS + ctx] = m < a.M ? job.x[m * job.xs + k] : 0.f;
-        }
-        for (int i = tid; i < 32 * 16; i += 64 * NW) {
-            const int ctx = i >> 4, o = i & 15;
-            const int64_t m = mbase + ctx;
-            dT[o * CS + ctx] = (m < a.M && o < job.count) ? job.d[m * job.dstr + o] : 0.f;
-        }
-        for (int i = tid; i < 32 * H; i += 64 * NW) {
-            const int ctx = i / H, j = i - ctx * H;
-            const int64_t m = mbase + ctx;
-            hT[j * CS + ctx] = m < a.M ? a.h[m * a.ldh + j] : 0.f;
-        }
-        __syncthreads();
-        h8 Bh[JT], Bl[JT];
+        if (st + gridDim.y < nsteps) fetch((st + gridDim.y) * CH);  // in flight during the MFMAs below
+#endif
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-            csplit8(*reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + 8 * q),
-                    *reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + 8 * q + 4), Bh[jt], Bl[jt]);
-        const f4 d0 = *reinterpret_cast<const f4*>(dT + r * CS + 8 * q);
-        const f4 d1 = *reinterpret_cast<const f4*>(dT + r * CS + 8 * q + 4);
+        for (int sub = 0; sub < CH / 32; ++sub) {
+            const int co = 32 * sub + 8 * q;
+            h8 Bh[JT], Bl[JT];
 #pragma unroll
-        for (int i = 0; i < IPW; ++i) {
-            const int k = wave + i * NW;
-            if (k < items) {  // wave-uniform
-                const f4 a0 = *reinterpret_cast<const f4*>(xT + k * CS + 8 * q) * d0;
-                const f4 a1 = *reinterpret_cast<const f4*>(xT + k * CS + 8 * q + 4) * d1;
-                gb[i] += (a0[0] + a0[1]) + (a0[2] + a0[3]) + (a1[0] + a1[1]) + (a1[2] + a1[3]);
-                h8 ah, al;
-                csplit8(a0, a1, ah, al);
+            for (int jt = 0; jt < JT; ++jt)
+                csplit8(*reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + co),
+                        *reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + co + 4), Bh[jt], Bl[jt]);
+            const f4 d0 = *reinterpret_cast<const f4*>(dT + r * CS + co);
+            const f4 d1 = *reinterpret_cast<const f4*>(dT + r * CS + co + 4);
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    acc[i][jt] = cmfma32h(ah, Bh[jt], acc[i][jt]);
-                    acc[i][jt] = cmfma32h(al, Bh[jt], acc[i][jt]);
-                    acc[i][jt] = cmfma32h(ah, Bl[jt], acc[i][jt]);
+            for (int i = 0; i < IPW; ++i) {
+                const int k = wave + i * NW;
+                if (k < items) {  // wave-uniform
+                    const f4 a0 = *reinterpret_cast<const f4*>(xT + k * CS + co) * d0;
+                    const f4 a1 = *reinterpret_cast<const f4*>(xT + k * CS + co + 4) * d1;
+                    gb[i] += (a0[0] + a0[1]) + (a0[2] + a0[3]) + (a1[0] + a1[1]) + (a1[2] + a1[3]);
+                    h8 ah, al;
+#if TNF_COND_ABLATE == 4  // timing experiment: no operand split
+                    ah = al = __builtin_bit_cast(h8, (u4){__float_as_uint(a0[0]), __float_as_uint(a0[1]), __float_as_uint(a1[0]), __float_as_uint(a1[1])});
+#else
+                    csplit8(a0, a1, ah, al);
+#endif
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        acc[i][jt] = cmfma32h(ah, Bh[jt], acc[i][jt]);
+                        acc[i][jt] = cmfma32h(al, Bh[jt], acc[i][jt]);
+                        acc[i][jt] = cmfma32h(ah, Bl[jt], acc[i][jt]);
+                    }
                 }
             }
         }
@@ -602,10 +701,10 @@ int64_t cond_flow_bwd_workspace(int D, int S, int L, int U, int H) {
 
 template <int DT, int KS, int BT, int NW>
 static int launch_bwd_variant(const CondBwdArgs& a, hipStream_t st) {
-    typedef TileStream<KS * 128 + 4, kCondG<KS>, 64 * NW> PStream;
-    typedef TileStream<KS * 256, 4 / KS, 64 * NW> TStream;
+    typedef TileStream<KS * 128 + 4, kCondG<KS>, NW, 2> PStream;
+    typedef TileStream<KS * 256, 4 / KS, NW, 2> TStream;
     constexpr int D = 16 * DT;
-    const size_t smem = (size_t)2 * (PStream::CHUNK_U4 + TStream::CHUNK_U4) * 16 + (size_t)NW * 16 * BT * (D + 4) * 4;
+    const size_t smem = (size_t)(PStream::LDS_U4 + TStream::LDS_U4) * 16 + (size_t)NW * 16 * BT * (D + 4) * 4;
     auto k = cond_flow_bwd_kernel<DT, KS, BT, NW>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -619,12 +718,18 @@ static int launch_bwd_variant(const CondBwdArgs& a, hipStream_t st) {
 template <int DT, int KS>
 static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) {
     int v = g_cond_variant;
-    if (v == 0) v = a.M >= 256 * 128 ? 3 : 1;
-    int rc = v >= 2 ? launch_bwd_variant<DT, KS, 2, 8>(a, st) : launch_bwd_variant<DT, KS, 1, 4>(a, st);
+    // (BT 1, 8 waves) beats (BT 2, 8 waves) here: the latter spills (the g_h accumulators, two operand
+    // slots and the gathered deltas do not fit 256 VGPRs at two waves per SIMD)
+    if (v == 0) v = a.M >= 256 * 128 ? 2 : 1;
+    int rc;
+    if (v == 4) rc = launch_bwd_variant<DT, KS, 2, 4>(a, st);
+    else if (v == 3) rc = launch_bwd_variant<DT, KS, 2, 8>(a, st);
+    else if (v == 2) rc = launch_bwd_variant<DT, KS, 1, 8>(a, st);
+    else rc = launch_bwd_variant<DT, KS, 1, 4>(a, st);
     if (rc) return rc;
     const CondCfg& c = g.cfg;
     const int jobs = c.S * (2 * 2 * (c.L + c.HT) + 2 * c.DT);
-    const int64_t nchunks = (a.M + 31) / 32;
+    const int64_t nchunks = (a.M + (KS == 4 ? 63 : 127)) / (KS == 4 ? 64 : 128);
     int64_t split = 2048 / jobs;
     if (split < 1) split = 1;
     if (split > nchunks) split = nchunks;

@@ -1,6 +1,9 @@
 // Shared pieces of the conditional-flow kernels (cond_flow.hip: forward, cond_flow_bwd.hip: backward):
 // split-f16 helpers, the tile program, the LDS tile stream and the per-tile MFMA.
 #pragma once
+#ifndef TNF_COND_ABLATE
+#define TNF_COND_ABLATE 0
+#endif
 #include "mfma_tile.h"
 #include "tnf_common.h"
 
@@ -142,78 +145,145 @@ __device__ __forceinline__ float cond_scale(unsigned maxbits) {
     return ldexpf(1.f, 13 - ilogbf(mx));
 }
 
-// the workgroup's view of the image: chunks of G tiles, double-buffered in LDS
-template <int TILE_U4_, int G, int NTHREADS>
+// The workgroup's view of an operand image: chunks of G tiles in a ring of NS LDS slots, filled by LDS-DMA
+// (global_load_lds_dwordx4: 1 KB per wave-instruction, no staging registers, lane-linear destination =
+// a plain contiguous copy).  On entering chunk c -- after the barrier that proves every wave is done
+// with chunk c-1 -- the copy of chunk c+NS-1 is requested into the slot just vacated, so NS-1 chunks are
+// in flight: the image streams from L2 / Infinity Cache with ~2 us latency under load, several chunks of
+// MFMA work.  The wait before the barrier is a COUNTED vmcnt (the NS-2 newer copies stay in flight; a
+// plain __syncthreads() would drain them with vmcnt(0)) followed by a raw s_barrier.
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int TILE_U4_, int G, int NW, int NS>
 struct TileStream {
     static constexpr int TILE_U4 = TILE_U4_;
     static constexpr int CHUNK_U4 = G * TILE_U4;
-    static constexpr int PF = (CHUNK_U4 + NTHREADS - 1) / NTHREADS;
+    static constexpr int NI = (CHUNK_U4 + 63) / 64;  // wave-instructions per chunk
+    static constexpr int SLOT_U4 = NI * 64;          // slot size: the tail instruction runs into padding
+    static constexpr int LDS_U4 = NS * SLOT_U4;
+    static constexpr int KEEP = (NS - 2) * (NI / NW);  // copies every wave may leave in flight at a barrier
     const u4* img;
     u4* stg;
     int64_t total_u4;
-    int t;
-    u4 pf[PF];
+    int in, chunk, rslot;
 
-    __device__ __forceinline__ void fetch(int chunk) {
-        const int64_t base = (int64_t)chunk * CHUNK_U4;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            int64_t g = base + threadIdx.x + i * NTHREADS;
-            g = g < total_u4 ? g : total_u4 - 1;  // clamped, never predicated (see ld_sel)
-            pf[i] = img[g];
+    __device__ __forceinline__ void copy(int c, int slot) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        u4* dst = stg + slot * SLOT_U4;
+        const int64_t base = (int64_t)c * CHUNK_U4;
+        for (int i = wave; i < NI; i += NW) {
+            int64_t g = base + i * 64 + lane;
+            g = g < total_u4 ? g : total_u4 - 1;  // clamped: past the end the data is never used
+            __builtin_amdgcn_global_load_lds(img + g, (lds_void*)(dst + i * 64), 16, 0, 0);
         }
     }
-    __device__ __forceinline__ void commit(int chunk) {
-        u4* dst = stg + (chunk & 1) * CHUNK_U4;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int idx = threadIdx.x + i * NTHREADS;
-            if (idx < CHUNK_U4) dst[idx] = pf[i];
-        }
+    __device__ __forceinline__ void arrive() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
     }
     __device__ __forceinline__ void init(const u4* image, u4* stage, int64_t tiles) {
         img = image;
         stg = stage;
         total_u4 = tiles * TILE_U4;
-        t = 0;
-        fetch(0);
-        commit(0);
-        __syncthreads();
-        fetch(1);
+        in = 0;
+        chunk = 0;
+        rslot = 0;
+#pragma unroll
+        for (int c = 0; c < NS - 1; ++c) copy(c, c);
+        arrive();
+        copy(NS - 1, NS - 1);
     }
     // every wave of the workgroup calls next() the same number of times, in the same order
     __device__ __forceinline__ const u4* next() {
-        const int chunk = t / G, in = t - chunk * G;
-        if (in == 0 && t > 0) {
-            commit(chunk);   // safe: all waves left chunk-2 (same buffer) before the previous barrier
-            __syncthreads();
-            fetch(chunk + 1);
+        if (in == G) {
+            in = 0;
+#if TNF_COND_ABLATE != 2  // timing experiment 2: no ring advance (no barrier, no copies)
+            ++chunk;
+            const int vacated = rslot;
+            rslot = rslot + 1 == NS ? 0 : rslot + 1;
+            arrive();
+            copy(chunk + NS - 1, vacated);
+#endif
         }
-        ++t;
-        return stg + (chunk & 1) * CHUNK_U4 + in * TILE_U4;
+        const u4* p = stg + rslot * SLOT_U4 + in * TILE_U4;
+        ++in;
+        return p;
     }
 };
 
-template <int KS, int BT>
-__device__ __forceinline__ void tile_gemm(const u4* tp, int lane, const h8 (&bh)[BT][KS], const h8 (&bl)[BT][KS],
-                                          f4 (&P)[BT]) {
-    const f4 c0 = *reinterpret_cast<const f4*>(tp + KS * 128 + (lane >> 4));
-#pragma unroll
-    for (int bt = 0; bt < BT; ++bt) P[bt] = c0;
+// fast transcendental forms (v_exp_f32 / v_rcp_f32 / v_log_f32, ~1 ulp): the precise library versions
+// cost ~50 VALU instructions each and, with two waves per SIMD, that is time the matrix pipe idles
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * sig2(kTwoLog2e * x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(kLog2e * x); }
+__device__ __forceinline__ float fast_log(float x) { return kLn2 * __builtin_amdgcn_logf(x); }
+
+// MFMA A operands of one tile (split-f16 halves per K step) + the accumulator's initial value
+template <int KS>
+struct TileOps {
+    u4 a[KS][2];
+    f4 c0;
+};
+template <int KS>
+__device__ __forceinline__ void load_ops(TileOps<KS>& o, const u4* tp, int lane) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        const h8 ah = __builtin_bit_cast(h8, tp[(ks * 2 + 0) * 64 + lane]);
-        const h8 al = __builtin_bit_cast(h8, tp[(ks * 2 + 1) * 64 + lane]);
+        o.a[ks][0] = tp[(ks * 2 + 0) * 64 + lane];
+        o.a[ks][1] = tp[(ks * 2 + 1) * 64 + lane];
+    }
+    o.c0 = *reinterpret_cast<const f4*>(tp + KS * 128 + (lane >> 4));
+}
+template <int KS, int BT>
+__device__ __forceinline__ void gemm_ops(const TileOps<KS>& o, const h8 (&bh)[BT][KS], const h8 (&bl)[BT][KS],
+                                         f4 (&P)[BT]) {
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) P[bt] = o.c0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const h8 ah = __builtin_bit_cast(h8, o.a[ks][0]);
+        const h8 al = __builtin_bit_cast(h8, o.a[ks][1]);
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) P[bt] = cmfma32h(ah, bh[bt][ks], P[bt]);
+#if TNF_COND_ABLATE != 1  // timing experiment 1: one MFMA per K step instead of three
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) P[bt] = cmfma32h(ah, bl[bt][ks], P[bt]);
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) P[bt] = cmfma32h(al, bh[bt][ks], P[bt]);
+#endif
     }
 }
 
+// Two-slot operand pipe over a TileStream: tiles alternate between the slots (every tile sequence of the
+// programs is made of [t net, s net] pairs), and a slot is refilled from LDS right after its MFMAs were
+// issued, one tile-time before it is needed again.
+template <int KS, int BT, typename Stream>
+struct TilePipe {
+    Stream ts;
+    TileOps<KS> op0, op1;
+    __device__ __forceinline__ void init(const u4* image, u4* stage, int64_t tiles, int lane) {
+        ts.init(image, stage, tiles);
+        load_ops<KS>(op0, ts.next(), lane);
+        load_ops<KS>(op1, ts.next(), lane);
+    }
+    __device__ __forceinline__ void gemm0(int lane, const h8 (&bh)[BT][KS], const h8 (&bl)[BT][KS], f4 (&P)[BT]) {
+        gemm_ops<KS, BT>(op0, bh, bl, P);
+        load_ops<KS>(op0, ts.next(), lane);
+    }
+    // slot 1 is refilled by the caller AFTER it consumed the pair's results (refill1): LDS returns in order
+    // and hipcc waits lgkmcnt(0) for the scalar inputs of that consumption, so a refill issued before it
+    // would be waited for on the spot; issued after, it has the next pair's slot-0 MFMAs to land
+    __device__ __forceinline__ void gemm1(int lane, const h8 (&bh)[BT][KS], const h8 (&bl)[BT][KS], f4 (&P)[BT]) {
+        gemm_ops<KS, BT>(op1, bh, bl, P);
+    }
+    __device__ __forceinline__ void refill1(int lane) { load_ops<KS>(op1, ts.next(), lane); }
+    __device__ __forceinline__ void skip1(int lane) { load_ops<KS>(op1, ts.next(), lane); }  // = refill1
+    __device__ __forceinline__ void skip_pair(int lane) {
+        load_ops<KS>(op0, ts.next(), lane);
+        load_ops<KS>(op1, ts.next(), lane);
+    }
+};
+
 template <int KS> constexpr int kCondG = 8 / KS;  // tiles per LDS chunk (~16.5 KB)
+// ring depth of the forward stream: 3 slots when the 160 KB of LDS allow it next to the waves' state
+template <int KS, int BT, int NW> constexpr int kCondNS = (NW * BT <= 16) ? 3 : 2;
 
 int launch_cond_image(const float* W, const float* b, int64_t ldw, const CondCfg& cfg, void* ws, void* image,
                       int backward_order, hipStream_t st);
