@@ -536,10 +536,13 @@ cond_gw_kernel(GwArgs a) {
     constexpr int CH = KS == 4 ? 64 : 128;        // contexts staged per step
     constexpr int CS = CH + 4;                    // padded row stride of the transposed staging buffers
     constexpr int XQ = Hd / 4;                    // float4 per context row, at most
-    constexpr int NX = (CH * XQ + NT - 1) / NT, ND = (CH * 4 + NT - 1) / NT, NH = (CH * (H / 4) + NT - 1) / NT;
+    constexpr int NX = (CH * XQ + NT - 1) / NT, ND = (CH * 4 + NT - 1) / NT;
+    constexpr int NHP = (CH / 8 * H + NT - 1) / NT;  // (hidden unit, context octet) pairs per thread
     __shared__ __attribute__((aligned(16))) float xT[(Hd + 1) * CS];
     __shared__ __attribute__((aligned(16))) float dT[16 * CS];
-    __shared__ __attribute__((aligned(16))) float hT[H * CS];
+    // h as ready MFMA B operands, split once per step for all waves: [sub-step][jt][hi/lo][lane], lane
+    // (j = lane & 15, q = lane >> 4) = contexts 8q..8q+7 of hidden unit 16 jt + j
+    __shared__ __attribute__((aligned(16))) u4 hB[(CH / 32) * JT * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const GwJob job = gw_job(a, blockIdx.x);
@@ -557,7 +560,8 @@ cond_gw_kernel(GwArgs a) {
     for (int i = tid; i < CS; i += NT) xT[job.d_in * CS + i] = 1.f;  // the bias item multiplies by one
 
     // register-staged prefetch of one step: x rows, delta rows, h rows of CH contexts (zero past M)
-    f4 px[NX], pd[ND], ph[NH];
+    f4 px[NX], pd[ND];
+    float ph[NHP][8];
     auto fetch = [&](int64_t mbase) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -578,13 +582,16 @@ cond_gw_kernel(GwArgs a) {
             pd[i] = ok ? v : zero;
         }
 #pragma unroll
-        for (int i = 0; i < NH; ++i) {
+        for (int i = 0; i < NHP; ++i) {
             const int idx = tid + i * NT;
-            const int ctx = idx / (H / 4), j4 = idx - ctx * (H / 4);
-            const int64_t m = mbase + ctx;
-            const bool ok = ctx < CH && m < a.M;
-            const f4 v = *reinterpret_cast<const f4*>(a.h + (ok ? m : 0) * a.ldh + 4 * j4);
-            ph[i] = ok ? v : zero;
+            const int oct = idx / H, j = idx - oct * H;  // consecutive threads -> consecutive hidden units
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t m = mbase + 8 * oct + e;
+                const bool ok = oct < CH / 8 && m < a.M;
+                const float v = a.h[(ok ? m : 0) * a.ldh + j];
+                ph[i][e] = ok ? v : 0.f;
+            }
         }
     };
     auto commit = [&]() {
@@ -608,12 +615,15 @@ cond_gw_kernel(GwArgs a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NH; ++i) {
+        for (int i = 0; i < NHP; ++i) {
             const int idx = tid + i * NT;
-            const int ctx = idx / (H / 4), j4 = idx - ctx * (H / 4);
-            if (ctx < CH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hT[(4 * j4 + e) * CS + ctx] = ph[i][e];
+            const int oct = idx / H, j = idx - oct * H;
+            if (oct < CH / 8) {
+                h8 hi, lo;
+                csplit8((f4){ph[i][0], ph[i][1], ph[i][2], ph[i][3]}, (f4){ph[i][4], ph[i][5], ph[i][6], ph[i][7]}, hi, lo);
+                const int slot = (((oct >> 2) * JT + (j >> 4)) * 2) * 64 + (j & 15) + 16 * (oct & 3);
+                hB[slot] = __builtin_bit_cast(u4, hi);
+                hB[slot + 64] = __builtin_bit_cast(u4, lo);
             }
         }
     };
@@ -638,9 +648,10 @@ cond_gw_kernel(GwArgs a) {
             const int co = 32 * sub + 8 * q;
             h8 Bh[JT], Bl[JT];
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-                csplit8(*reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + co),
-                        *reinterpret_cast<const f4*>(hT + (16 * jt + r) * CS + co + 4), Bh[jt], Bl[jt]);
+            for (int jt = 0; jt < JT; ++jt) {
+                Bh[jt] = __builtin_bit_cast(h8, hB[((sub * JT + jt) * 2 + 0) * 64 + lane]);
+                Bl[jt] = __builtin_bit_cast(h8, hB[((sub * JT + jt) * 2 + 1) * 64 + lane]);
+            }
             const f4 d0 = *reinterpret_cast<const f4*>(dT + r * CS + co);
             const f4 d1 = *reinterpret_cast<const f4*>(dT + r * CS + co + 4);
 #pragma unroll
