@@ -252,6 +252,23 @@ int tnf_to_simplex(int32_t dtype, const void* z, void* z_out, void* log_det, int
 int tnf_to_simplex_backward(int32_t dtype, const void* z, const void* g_z_out, const void* g_log_det, void* g_z,
                             int64_t rows, int32_t D_in, int32_t D_attr, void* stream);
 
+/* ---- flow level, arch_type "AR": [MAF, BatchNorm, Affine] (density_estimator.py:271-274), float32 ---- */
+/* One kernel per call: the Affine and the cached-statistics BatchNorm fold into a per-feature FMA in front of
+ * (log_prob: Affine^-1, BN^-1, MAF^-1, base density; :390-416) or behind (frozen forward: MAF, BN, Affine;
+ * :374-388 with use_last=True) the MAF kernel.  params rows: [MAF | alpha (D) | shift (D)]; bn_mean /
+ * bn_alpha (D).  tnf_ar_flow_log_prob_f32: any of log_prob, z0, sum_log_det may be NULL (not all).
+ * Supported (tnf_ar_flow_supported): D <= 64, num_units <= 64, num_layers <= 5. */
+int tnf_ar_flow_supported(int32_t D, int32_t num_layers, int32_t num_units);
+int64_t tnf_ar_flow_workspace_bytes(int64_t M_p, int32_t D);
+int tnf_ar_flow_log_prob_f32(const float* z, const float* params, const float* masks, const float* bn_mean,
+                             const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, int64_t M_z,
+                             int64_t M_p, int64_t N, int32_t D, int32_t num_layers, int32_t num_units,
+                             int64_t params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
+int tnf_ar_flow_forward_f32(const float* omega, const float* params, const float* masks, const float* bn_mean,
+                            const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z, int64_t M_p,
+                            int64_t N, int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Base density of NormFlow.forward, float64 like the reference's numpy expression
  * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as
  * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)) in float64.  omega (rows, D) of `dtype` (TNF_F64 for

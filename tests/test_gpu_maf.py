@@ -100,3 +100,76 @@ def test_reference_self_consistency_ar(tnf):
         log_q_inv = nf.log_prob(z)
     assert z.shape == (1, 10, 4) and log_q.shape == (1, 10)
     assert float(((log_q.cpu().double() - log_q_inv.cpu().double()) ** 2).sum()) < 1e-2
+
+
+@pytest.mark.parametrize("D,L,U,Mz,Mp,N", [
+    (4, 2, 20, 1, 1, 1000), (5, 1, 15, 2, 2, 77), (7, 3, 33, 1, 3, 50), (16, 2, 32, 1, 1, 257),
+    (2, 2, 15, 3, 1, 19), (64, 2, 64, 1, 1, 130), (33, 2, 40, 2, 2, 31), (12, 5, 17, 1, 1, 64),
+])
+def test_maf_mfma_vs_oracle(tnf, oracle, D, L, U, Mz, Mp, N):
+    """The matrix-pipe MAF kernel (float32, any D <= 64 incl. D % 4 != 0, per-context parameter rows) against the
+    CPU oracle in both directions, and against the shape-generic kernel (TNF_OPT_FORCE_GENERIC)."""
+    from torch_nf_amd import _lib
+
+    np.random.seed(D * 100 + U)
+    layer = tnf.MAF(D, L, U)
+    L, U = layer.num_layers, layer.num_units
+    rng = np.random.RandomState(3)
+    # weight scale ~ 1/sqrt(fan-in) keeps the pre-activations O(1): z' = (z - mu) e^-alpha is ill-conditioned otherwise
+    params = torch.tensor(rng.normal(0, 0.4 / np.sqrt(max(1.0, U / 16.0)), (Mp, layer.count_num_params())), dtype=torch.float32)
+    z = torch.tensor(rng.normal(0, 1, (Mz, N, D)), dtype=torch.float32)
+    Ms = [M[0].numpy() for M in layer.Ms]
+    assert bool(_lib.lib.tnf_ar_flow_supported(D, L, U))
+    for inverse in (True, False):
+        ref_z, ref_ld = oracle.maf(z, params, D, L, U, Ms, inverse)
+        fn = layer.inverse_and_log_det if inverse else layer.forward_and_log_det
+        got_z, got_ld = fn(z.cuda(), params.cuda())
+        _lib.lib.tnf_set_option(_lib.OPT_FORCE_GENERIC, 1)
+        try:
+            gen_z, gen_ld = fn(z.cuda(), params.cuda())
+        finally:
+            _lib.lib.tnf_set_option(_lib.OPT_FORCE_GENERIC, 0)
+        # the sampling direction iterates the nets D-1 times: errors compound with D
+        tol = dict(rtol=2e-5, atol=2e-5) if inverse else dict(rtol=1e-4 * max(1, D // 8), atol=1e-4 * max(1, D // 8))
+        torch.testing.assert_close(got_z.cpu(), ref_z, **tol)
+        torch.testing.assert_close(got_ld.cpu(), ref_ld, **tol)
+        torch.testing.assert_close(got_z, gen_z, **tol)
+        torch.testing.assert_close(got_ld, gen_ld, **tol)
+
+
+def test_ar_flow_fused_paths(tnf, oracle):
+    """NormFlow('AR') as ONE kernel (tnf_ar_flow_log_prob_f32 / tnf_ar_flow_forward_f32) vs the oracle and vs the
+    per-bijector composition; per-context parameter rows; N = 2^18 consistency of forward and log_prob."""
+    for D, L, U, M, N in [(4, 2, 20, 1, 500), (10, 2, 32, 3, 65), (64, 1, 64, 1, 100)]:
+        np.random.seed(D)
+        torch.manual_seed(D)
+        nf = tnf.NormFlow(D, True, "AR", 1, L, U)
+        g = torch.Generator().manual_seed(D)
+        nf.bijectors[1].set_last_stats(torch.randn(D, generator=g) * 0.1, torch.rand(D, generator=g) * 0.5 + 0.75)
+        params = (torch.randn(M, nf.D_params, generator=g) * 0.3).cuda()
+        z = torch.randn(M, N, D, generator=g).cuda()
+        Ms = [Mk[0].numpy() for Mk in nf.bijectors[0].Ms]
+        stat = (nf.bijectors[1].get_last_mean().cpu().float(), nf.bijectors[1].get_last_alpha().cpu().float())
+        with torch.no_grad():
+            assert nf._ar_fused_ok(z, params)
+            lp = nf.log_prob(z, params)
+            z0, sld = nf.inverse_and_log_det(z, params)
+            zf, lq = nf._forward_from(z, params, freeze_bn=True)
+        ref_lp = oracle.ar_flow_log_prob(z.cpu(), params.cpu(), D, L, U, Ms, stat)
+        torch.testing.assert_close(lp.cpu(), ref_lp, rtol=1e-5, atol=2e-5)
+        ref = -0.5 * (z0 ** 2).sum(2) - D * np.log(np.sqrt(2 * np.pi)) - sld
+        torch.testing.assert_close(lp, ref, rtol=1e-5, atol=2e-5)
+        # frozen forward vs the per-bijector composition of the same package (autograd mode switches paths)
+        p2 = params.clone().requires_grad_()
+        zf2, lq2 = nf._forward_from(z, p2, freeze_bn=True)
+        tol = 1e-4 * max(1, D // 8)
+        torch.testing.assert_close(zf, zf2.detach(), rtol=tol, atol=tol)
+        torch.testing.assert_close(lq, lq2.detach(), rtol=1e-5, atol=tol)
+    # forward -> log_prob consistency at N = 2^18 (the reference's own AR check, size-independent)
+    np.random.seed(0)
+    nf = tnf.NormFlow(8, False, "AR", 1, 2, 32)
+    with torch.no_grad():
+        nf(64)  # sets BatchNorm statistics
+        z, log_q = nf.sample(1 << 18)
+        lp = nf.log_prob(z)
+    assert float((log_q.float() - lp).abs().max()) < 5e-3

@@ -302,11 +302,24 @@ class MAF(Bijector):
         self.Ms = [torch.tensor(M[None, :, :]).float() for M in Ms]
         self._masks_flat = torch.cat([torch.tensor(M).float().reshape(-1) for M in Ms])
 
+    def _masks_for(self, dtype):
+        """The concatenated layer masks on the compute device in `dtype` (uploaded once, then cached)."""
+        from . import _lib
+
+        key = (_lib.require_device(), dtype)
+        cache = self.__dict__.setdefault("_masks_dev", {})
+        if cache.get("src") is not self._masks_flat:  # set_masks() installed new masks
+            cache.clear()
+            cache["src"] = self._masks_flat
+        if key not in cache:
+            cache[key] = self._masks_flat.to(device=key[0], dtype=dtype).contiguous()
+        return cache[key]
+
     def forward_and_log_det(self, z, params):
-        return ops.maf(z, params, self._masks_flat, self.D, self.num_layers, self.num_units, False)
+        return ops.maf(z, params, self._masks_for(z.dtype), self.D, self.num_layers, self.num_units, False)
 
     def inverse_and_log_det(self, z, params):
-        return ops.maf(z, params, self._masks_flat, self.D, self.num_layers, self.num_units, True)
+        return ops.maf(z, params, self._masks_for(z.dtype), self.D, self.num_layers, self.num_units, True)
 
     def count_num_params(self):
         return int(2 * (2 * self.D * self.num_units + (self.num_layers - 1) * (self.num_units ** 2)))

@@ -271,7 +271,68 @@ int tnf_maf(int32_t dtype, const void* z, const void* params, const void* masks,
                     (long long)tnf_maf_num_params(D, L, U));
     if (!z || !params || !masks || !z_out || !log_det) return fail(TNF_EINVAL, "tnf_maf: NULL pointer");
     if (N == 0) return TNF_OK;
+    if (dtype == TNF_F32 && !g_force_generic && maf_mfma_supported(D, L, U)) {
+        MafArgs a = {};
+        a.z = (const float*)z; a.z_out = (float*)z_out; a.params = (const float*)params; a.masks = (const float*)masks;
+        a.pstride = pstride; a.ld_out = (float*)log_det; a.ld_sign = 1.f;
+        a.Mz = M_z; a.Mp = M_p; a.N = N; a.D = D; a.L = L; a.U = U; a.inverse = inverse;
+        return launch_maf_mfma(a, as_stream(stream));
+    }
     return launch_maf(dtype, z, params, masks, z_out, log_det, M_z, M_p, N, D, L, U, inverse, pstride, as_stream(stream));
+}
+
+int tnf_ar_flow_supported(int32_t D, int32_t L, int32_t U) { return maf_mfma_supported(D, L, U) ? 1 : 0; }
+
+int64_t tnf_ar_flow_workspace_bytes(int64_t M_p, int32_t D) {
+    if (M_p < 1 || D < 1) return fail(TNF_EINVAL, "tnf_ar_flow_workspace_bytes: M_p=%lld D=%d", (long long)M_p, D);
+    return round16(M_p * (2 * (int64_t)D + 1) * (int64_t)sizeof(float));
+}
+
+static int ar_flow_run(const char* fn, int inverse, const float* z, const float* params, const float* masks,
+                       const float* bn_mean, const float* bn_alpha, float* z_out, float* sum_log_det, float* log_prob,
+                       int64_t M_z, int64_t M_p, int64_t N, int D, int L, int U, int64_t pstride, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+    int rc = check_mnd(fn, M_z, M_p, N, D);
+    if (rc) return rc;
+    if (!maf_mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "%s: no kernel for D=%d L=%d U=%d", fn, D, L, U);
+    const int64_t p_maf = tnf_maf_num_params(D, L, U);
+    if (pstride < p_maf + 2 * (int64_t)D)
+        return fail(TNF_EINVAL, "%s: params row has %lld elements, the flow needs %lld", fn, (long long)pstride,
+                    (long long)(p_maf + 2 * D));
+    if (!z || !params || !masks || !bn_mean || !bn_alpha || !workspace) return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    if (workspace_bytes < tnf_ar_flow_workspace_bytes(M_p, D))
+        return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)workspace_bytes,
+                    (long long)tnf_ar_flow_workspace_bytes(M_p, D));
+    if (N == 0) return TNF_OK;
+    float* fold = (float*)workspace;
+    float* ldc = fold + M_p * 2 * (int64_t)D;
+    rc = launch_ar_fold(params, pstride, p_maf, bn_mean, bn_alpha, fold, ldc, M_p, D, inverse, as_stream(stream));
+    if (rc) return rc;
+    MafArgs a = {};
+    a.z = z; a.z_out = z_out; a.params = params; a.masks = masks; a.pstride = pstride;
+    if (inverse) a.pre = fold; else a.post = fold;
+    a.fold_stride = 2 * (int64_t)D;
+    a.ld_out = sum_log_det; a.ld_sign = 1.f; a.ldc = ldc; a.add_ldc = 1; a.log_prob = log_prob;
+    a.Mz = M_z; a.Mp = M_p; a.N = N; a.D = D; a.L = L; a.U = U; a.inverse = inverse;
+    return launch_maf_mfma(a, as_stream(stream));
+}
+
+int tnf_ar_flow_log_prob_f32(const float* z, const float* params, const float* masks, const float* bn_mean,
+                             const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, int64_t M_z,
+                             int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U, int64_t pstride, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    if (!log_prob && !z0 && !sum_log_det) return fail(TNF_EINVAL, "tnf_ar_flow_log_prob_f32: no output requested");
+    return ar_flow_run("tnf_ar_flow_log_prob_f32", 1, z, params, masks, bn_mean, bn_alpha, z0, sum_log_det, log_prob, M_z,
+                       M_p, N, D, L, U, pstride, workspace, workspace_bytes, stream);
+}
+
+int tnf_ar_flow_forward_f32(const float* omega, const float* params, const float* masks, const float* bn_mean,
+                            const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z, int64_t M_p, int64_t N,
+                            int32_t D, int32_t L, int32_t U, int64_t pstride, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+    if (!z_out || !sum_log_det) return fail(TNF_EINVAL, "tnf_ar_flow_forward_f32: NULL pointer");
+    return ar_flow_run("tnf_ar_flow_forward_f32", 0, omega, params, masks, bn_mean, bn_alpha, z_out, sum_log_det, nullptr,
+                       M_z, M_p, N, D, L, U, pstride, workspace, workspace_bytes, stream);
 }
 
 int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,

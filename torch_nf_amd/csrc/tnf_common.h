@@ -193,6 +193,29 @@ int launch_to_simplex(int dtype, const void* z, void* z_out, void* log_det, int6
                       hipStream_t st);
 int launch_to_simplex_backward(int dtype, const void* z, const void* g_zout, const void* g_ld, void* g_z, int64_t rows,
                                int Din, int Dc, hipStream_t st);
+// MAF on the matrix pipe (maf_mfma.hip): float32, D <= 64, U <= 64, L <= 5
+struct MafArgs {
+    const float* z;
+    float* z_out;        // may be NULL when only log_prob is wanted
+    const float* params;
+    const float* masks;
+    int64_t pstride;
+    const float* pre;    // [A (D) | B (D)] per parameter row, or NULL
+    const float* post;
+    int64_t fold_stride;
+    float* ld_out;       // (M, N) or NULL: ld_sign * sum(alpha) (+ ldc[m] when add_ldc)
+    float ld_sign;
+    const float* ldc;
+    int add_ldc;
+    float* log_prob;     // (M, N) or NULL: -|z'|^2/2 - D log sqrt(2 pi) - (ld_sign * sum(alpha) + ldc[m])
+    int64_t Mz, Mp, N;
+    int D, L, U, inverse;
+};
+
+bool maf_mfma_supported(int D, int L, int U);
+int launch_maf_mfma(const MafArgs& a, hipStream_t st);
+int launch_ar_fold(const float* params, int64_t pstride, int64_t p_maf, const float* bn_mean, const float* bn_alpha,
+                   float* fold, float* ldc, int64_t Mp, int D, int inverse, hipStream_t st);
 int launch_maf(int dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
                int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st);
 int launch_maf_backward(int dtype, const void* z, const void* params, const void* masks, const void* g_zout,

@@ -173,6 +173,19 @@ class NormFlow(DensityEstimator):
             self.__dict__["_bn_cache"] = cached
         return cached[1], cached[2]
 
+    def _ar_fused_ok(self, z, params):
+        """[MAF, BatchNorm, Affine] as one kernel: float32, no autograd, shape covered by the MFMA MAF kernel."""
+        if self.arch_type != "AR" or z.dtype != torch.float32 or params.dtype != torch.float32:
+            return False
+        if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
+            return False
+        return z.dim() == 3 and ops.ar_flow_supported(self.D, self.num_layers, self.num_units)
+
+    def _ar_args(self):
+        maf, bn = self.bijectors[0], self.bijectors[1]
+        return (maf._masks_for(torch.float32), bn.get_last_mean().detach(), bn.get_last_alpha().detach(), self.D,
+                self.num_layers, self.num_units)
+
     def _fused_ok(self, z, params):
         """One-call fused path: coupling stack, float32, no autograd, MFMA-covered shape."""
         if self.arch_type != "coupling":
@@ -230,7 +243,10 @@ class NormFlow(DensityEstimator):
             log_q = ops.base_log_density_f64(omega64)
         p_dev = params if params.device == dev else params.to(dev)
 
-        if freeze_bn and self._fused_ok(z, p_dev):
+        if freeze_bn and self._ar_fused_ok(z, p_dev):
+            z, sld = ops.ar_flow_forward_raw(z, p_dev, *self._ar_args())
+            log_q = log_q - sld
+        elif freeze_bn and self._fused_ok(z, p_dev):
             mean, alpha = self._bn_stats(dev)
             z, sld = ops.flow_forward_raw(z, p_dev, mean, alpha, self.D, self.num_stages,
                                           self.num_layers, self.num_units, self.fusion)
@@ -256,6 +272,9 @@ class NormFlow(DensityEstimator):
     def inverse_and_log_det(self, z, params):
         """Map z back to the base space, accumulating the forward log-dets
         (density_estimator.py:390-406).  Returns (z0, sum_log_det float32 (M,N))."""
+        if self._n_core == len(self.bijectors) and self._ar_fused_ok(z, params):
+            _, z0, sld = ops.ar_flow_log_prob_raw(z, params, *self._ar_args(), want_lp=False, want_z0=True, want_sld=True)
+            return z0, sld
         if self._n_core == len(self.bijectors) and self._fused_ok(z, params):
             dev = _lib.require_device()
             mean, alpha = self._bn_stats(dev)
@@ -304,6 +323,8 @@ class NormFlow(DensityEstimator):
         return self._core_log_prob(z, params)
 
     def _core_log_prob(self, z, params):
+        if self._ar_fused_ok(z, params):
+            return ops.ar_flow_log_prob_raw(z, params, *self._ar_args())[0]
         if self._fused_ok(z, params):
             dev = _lib.require_device()
             mean, alpha = self._bn_stats(dev)

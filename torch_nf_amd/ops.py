@@ -431,7 +431,7 @@ def maf_raw(z, params, masks, D, L, U, inverse):
         raise TypeError("z (%s) and params (%s) must have the same dtype" % (z.dtype, params.dtype))
     zc = _stage(z, dev)
     pc, pstride = _rows(params, dev)
-    mk = _stage(masks.to(z.dtype), dev)
+    mk = masks if (masks.device == dev and masks.dtype == z.dtype) else _stage(masks.to(z.dtype), dev)
     Mz, N = zc.shape[0], zc.shape[1]
     Mp = pc.shape[0]
     M = _bcast_M(Mz, Mp)
@@ -688,3 +688,54 @@ class _CondFlowLogProbFn(torch.autograd.Function):
 
 def cond_flow_log_prob_train(z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U):
     return _CondFlowLogProbFn.apply(z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U)
+
+
+# ---------------------------------------------------------------------------
+# NormFlow(arch_type="AR") = [MAF, BatchNorm, Affine] in one kernel per call (float32, no autograd)
+# ---------------------------------------------------------------------------
+def ar_flow_supported(D, L, U):
+    return bool(lib.tnf_ar_flow_supported(D, L, U))
+
+
+def _ar_common(z, params, masks, bn_mean, bn_alpha, D):
+    _check3(z)
+    dev = _lib.require_device()
+    zc = _stage(z.detach(), dev)
+    pc, pstride = _rows(params.detach(), dev)
+    mk = masks if (masks.device == dev and masks.dtype == torch.float32) else _stage(masks.float(), dev)
+    mean, alpha = _stats(bn_mean.reshape(-1), dev), _stats(bn_alpha.reshape(-1), dev)
+    Mz, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    M = _bcast_M(Mz, Mp)
+    if zc.shape[2] != D:
+        raise ValueError("last dimension of z (%d) must equal D (%d)" % (zc.shape[2], D))
+    nbytes = check(lib.tnf_ar_flow_workspace_bytes(Mp, D))
+    return dev, zc, pc, pstride, mk, mean, alpha, Mz, Mp, M, N, _workspace(nbytes, dev), nbytes
+
+
+def ar_flow_log_prob_raw(z, params, masks, bn_mean, bn_alpha, D, L, U, want_lp=True, want_z0=False, want_sld=False):
+    """tnf_ar_flow_log_prob_f32 -> (log_prob | None, z0 | None, sum_log_det | None) on z's device."""
+    home = z.device
+    dev, zc, pc, pstride, mk, mean, alpha, Mz, Mp, M, N, ws, nbytes = _ar_common(z, params, masks, bn_mean, bn_alpha, D)
+    lp = torch.empty((M, N), dtype=torch.float32, device=dev) if want_lp else None
+    z0 = torch.empty((M, N, D), dtype=torch.float32, device=dev) if want_z0 else None
+    sld = torch.empty((M, N), dtype=torch.float32, device=dev) if want_sld else None
+    check(lib.tnf_ar_flow_log_prob_f32(zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), mean.data_ptr(), alpha.data_ptr(),
+                                       lp.data_ptr() if want_lp else None, z0.data_ptr() if want_z0 else None,
+                                       sld.data_ptr() if want_sld else None, Mz, Mp, N, D, L, U, pstride,
+                                       ws.data_ptr(), nbytes, _lib.stream_ptr()))
+    if home != dev:
+        lp, z0, sld = (t if t is None else t.to(home) for t in (lp, z0, sld))
+    return lp, z0, sld
+
+
+def ar_flow_forward_raw(omega, params, masks, bn_mean, bn_alpha, D, L, U):
+    """tnf_ar_flow_forward_f32 (cached BatchNorm statistics) -> (z, sum_log_det) on the compute device."""
+    dev, zc, pc, pstride, mk, mean, alpha, Mz, Mp, M, N, ws, nbytes = _ar_common(omega, params, masks, bn_mean,
+                                                                               bn_alpha, D)
+    z = torch.empty((M, N, D), dtype=torch.float32, device=dev)
+    sld = torch.empty((M, N), dtype=torch.float32, device=dev)
+    check(lib.tnf_ar_flow_forward_f32(zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), mean.data_ptr(), alpha.data_ptr(),
+                                      z.data_ptr(), sld.data_ptr(), Mz, Mp, N, D, L, U, pstride, ws.data_ptr(), nbytes,
+                                      _lib.stream_ptr()))
+    return z, sld
