@@ -44,14 +44,21 @@ with torch.no_grad():
         line("ToInterval inverse D=%d" % D, N, timeit(lambda: iv.inverse_and_log_det(y)), 8 * D + 4)
         sx = tnf.ToSimplex(D)
         line("ToSimplex forward D=%d" % D, N, timeit(lambda: sx(z)), 8 * D + 8)
-    for (D, L, U, N) in [(4, 2, 20, 1 << 20), (16, 2, 32, 1 << 18), (64, 2, 64, 1 << 16)]:
+    from torch_nf_amd import _lib
+    for (D, L, U, N) in [(4, 2, 20, 1 << 20), (16, 2, 32, 1 << 20), (64, 2, 64, 1 << 18)]:
+        np.random.seed(0)
         maf = tnf.MAF(D, L, U)
         p = torch.randn(1, maf.count_num_params(), device="cuda") * 0.2
         z = torch.randn(1, N, D, device="cuda")
-        line("MAF inverse D=%d L=%d U=%d" % (D, L, U), N, timeit(lambda: maf.inverse_and_log_det(z, p), 5), 8 * D + 4)
-        line("MAF forward (D-1 passes) D=%d" % D, N, timeit(lambda: maf(z, p), 3), 8 * D + 4)
+        for generic in (0, 1):  # matrix-pipe kernel, then the shape-generic one
+            _lib.lib.tnf_set_option(_lib.OPT_FORCE_GENERIC, generic)
+            tag = "generic" if generic else "mfma"
+            line("MAF inverse D=%d L=%d U=%d [%s]" % (D, L, U, tag), N, timeit(lambda: maf.inverse_and_log_det(z, p), 5), 8 * D + 4)
+            line("MAF forward (D-1 passes) D=%d [%s]" % (D, tag), N, timeit(lambda: maf(z, p), 3), 8 * D + 4)
+        _lib.lib.tnf_set_option(_lib.OPT_FORCE_GENERIC, 0)
         nf = tnf.NormFlow(D, False, "AR", 1, L, U)
-        line("NormFlow('AR').log_prob D=%d" % D, N, timeit(lambda: nf.log_prob(z), 5), 4 * D + 4)
+        line("NormFlow('AR').log_prob D=%d (one kernel)" % D, N, timeit(lambda: nf.log_prob(z), 5), 4 * D + 4)
+        line("NormFlow('AR').sample D=%d (one kernel)" % D, N, timeit(lambda: nf.sample(N), 3), 4 * D + 12)
     D, N = 64, 1 << 20
     lb = np.where(np.arange(D) % 3 == 0, -np.inf, -6.0)
     ub = np.where(np.arange(D) % 3 == 1, np.inf, 6.0)
