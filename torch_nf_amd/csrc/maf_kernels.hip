@@ -167,25 +167,24 @@ int launch_maf(int dtype, const void* z, const void* params, const void* masks, 
 // Backward of the inverse direction (what log_prob training differentiates):
 //   out = (z - mu) e^-alpha, ld = sum alpha
 //   dz = g e^-alpha + (nets' input gradient),  dmu = -g e^-alpha,  dalpha = -g out + g_ld
-// LDS: actx [TS][W] (= z), act[net][l = 1..L][TS][W], out[net][TS][W], delta[net][2][TS][W].
+// LDS: actx [TS][W] (= z), act[net][l = 1..L][TS][W], out[net][TS][W], delta[net][2][TS][W], and -- when it
+// fits (`lacc`) -- one accumulator per parameter: a workgroup then walks its tiles grid-stride, every
+// weight index is owned by one thread, and the parameter gradient leaves the workgroup once at the end
+// (plain stores when the workgroup owns its context's row, else one atomic per parameter per workgroup).
+// Without it every tile sends one atomic per parameter.
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
 maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const T* __restrict__ masks,
                     const T* __restrict__ g_zout, const T* __restrict__ g_ld, T* __restrict__ g_z,
                     T* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N, int D, int L, int U,
-                    int64_t pstride, int64_t gpstride, int TS, int W) {
+                    int64_t pstride, int64_t gpstride, int TS, int W, int lacc, int lw, int P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x;
     const int64_t m = grid_m();
     if (m >= M) return;
-    const int64_t n0 = (int64_t)blockIdx.x * TS;
-    const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
     const int64_t mp = Mp == 1 ? 0 : m;
-    const T* zt = z + (m * N + n0) * D;
-    const T* gzo = g_zout + (m * N + n0) * D;
-    T* gz = g_z + (m * N + n0) * D;
     const T* p0 = params + mp * pstride;
     T* gp0 = g_params + mp * gpstride;
     const int64_t plane = (int64_t)TS * W;
@@ -193,7 +192,33 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
     T* acts = smem + plane;                       // [2][L][TS][W]
     T* outb = acts + 2 * (int64_t)L * plane;      // [2][TS][W]  mu, alpha
     T* dlt = outb + 2 * plane;                    // [2][2][TS][W]
+    T* gacc = dlt + 4 * plane;                    // [P] when lacc
+    T* wl = gacc + (lacc ? P : 0);                // [P] when lw: the masked weights W * M of this parameter row
     auto act = [&](int net, int l) -> T* { return l == 0 ? actx : acts + ((int64_t)net * L + (l - 1)) * plane; };
+    if (lacc)
+        for (int i = tid; i < P; i += 256) gacc[i] = 0;
+    if (lw) {  // parameter index -> mask index: per layer [W_mu | W_alpha] share one mask
+        int64_t off = 0, moff = 0;
+        for (int l = 0; l <= L; ++l) {
+            const int64_t nw = (int64_t)((l == 0) ? D : U) * ((l == L) ? D : U);
+            for (int64_t i = tid; i < nw; i += 256) {
+                const T mv = masks[moff + i];
+                wl[off + i] = mv * p0[off + i];
+                wl[off + nw + i] = mv * p0[off + nw + i];
+            }
+            off += 2 * nw;
+            moff += nw;
+        }
+    }
+    const T* pw = lw ? wl : p0;  // weights as the loops below read them (masked already when lw)
+    const int64_t ntiles = (N + TS - 1) / TS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
+    const T* zt = z + (m * N + n0) * D;
+    const T* gzo = g_zout + (m * N + n0) * D;
+    T* gz = g_z + (m * N + n0) * D;
+    __syncthreads();  // the previous tile's readers are done with the activation planes
 
     for (int idx = tid; idx < ts * D; idx += 256) {
         const int i = idx / D, d = idx - i * D;
@@ -201,7 +226,7 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
     }
     __syncthreads();
     {   // forward recompute, keeping every activation
-        const T* p = p0;
+        const T* p = pw;
         const T* mk = masks;
         for (int l = 0; l <= L; ++l) {
             const int din = (l == 0) ? D : U, dout = (l == L) ? D : U;
@@ -216,6 +241,12 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
             for (int idx = tid; idx < ts * dout; idx += 256) {
                 const int i = idx / dout, o = idx - i * dout;
                 T am = 0, aa = 0;
+                if (lw) {
+                    for (int k = 0; k < din; ++k) {
+                        am += xm[i * W + k] * wm[k * dout + o];
+                        aa += xa[i * W + k] * wa[k * dout + o];
+                    }
+                } else
                 for (int k = 0; k < din; ++k) {
                     const T mv = mk[(int64_t)k * dout + o];
                     am += xm[i * W + k] * (mv * wm[(int64_t)k * dout + o]);
@@ -254,7 +285,7 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
             moff += (int64_t)di * U;
         }
         const int64_t nw = (int64_t)din * dout;
-        const T* wm = p0 + off;
+        const T* wm = pw + off;
         const T* wa = wm + nw;
         const T* mk = masks + moff;
         T* gwm = gp0 + off;
@@ -272,8 +303,13 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
                     am += xm[i * W + k] * dmc[i * W + o];
                     aa += xa[i * W + k] * dac[i * W + o];
                 }
-                atomicAdd(gwm + idx, mv * am);
-                atomicAdd(gwa + idx, mv * aa);
+                if (lacc) {  // idx is owned by this thread for every tile of the workgroup
+                    gacc[off + idx] += mv * am;
+                    gacc[off + nw + idx] += mv * aa;
+                } else {
+                    atomicAdd(gwm + idx, mv * am);
+                    atomicAdd(gwa + idx, mv * aa);
+                }
             }
         }
         if (l > 0) {
@@ -282,6 +318,12 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
             for (int idx = tid; idx < ts * din; idx += 256) {
                 const int i = idx / din, k = idx - i * din;
                 T am = 0, aa = 0;
+                if (lw) {
+                    for (int o = 0; o < dout; ++o) {
+                        am += wm[k * dout + o] * dmc[i * W + o];
+                        aa += wa[k * dout + o] * dac[i * W + o];
+                    }
+                } else
                 for (int o = 0; o < dout; ++o) {
                     const T mv = mk[(int64_t)k * dout + o];
                     am += mv * wm[(int64_t)k * dout + o] * dmc[i * W + o];
@@ -295,6 +337,9 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
             for (int idx = tid; idx < ts * din; idx += 256) {
                 const int i = idx / din, k = idx - i * din;
                 T a = 0;
+                if (lw) {
+                    for (int o = 0; o < dout; ++o) a += wm[k * dout + o] * dmc[i * W + o] + wa[k * dout + o] * dac[i * W + o];
+                } else
                 for (int o = 0; o < dout; ++o) {
                     const T mv = mk[(int64_t)k * dout + o];
                     a += mv * (wm[(int64_t)k * dout + o] * dmc[i * W + o] + wa[(int64_t)k * dout + o] * dac[i * W + o]);
@@ -304,6 +349,16 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
         }
         __syncthreads();
         cur ^= 1;
+    }
+    }  // tiles
+    if (lacc) {
+        __syncthreads();
+        const bool own = Mp > 1 && gridDim.x == 1;  // this workgroup is the only writer of its context's row
+        for (int i = tid; i < P; i += 256) {
+            const T v = gacc[i];
+            if (own) gp0[i] = v;
+            else if (v != (T)0) atomicAdd(gp0 + i, v);
+        }
     }
 }
 
@@ -315,21 +370,35 @@ int launch_maf_backward(int dtype, const void* z, const void* params, const void
     size_t smem;
     const int TS = maf_tile(D, U, L, esz, 1 + 2 * L + 2 + 4, N, &W, &smem);
     if (smem > 160 * 1024) return fail(TNF_EUNSUPPORTED, "maf_backward: layer width %d needs %zu B of LDS", W, smem);
-    const int64_t tiles = (N + TS - 1) / TS;
+    int64_t tiles = (N + TS - 1) / TS;
     if (tiles > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "maf_backward: grid too large");
+    // per-parameter accumulators in LDS when they fit next to the activation planes
+    const int64_t P = 2 * (2 * (int64_t)D * U + (int64_t)(L - 1) * U * U);
+    const int lw = smem + (size_t)P * esz <= 150 * 1024;  // the masked weights in LDS (first: it speeds every loop)
+    if (lw) smem += (size_t)P * esz;
+    const int lacc = smem + (size_t)P * esz <= 150 * 1024;
+    if (lacc) {
+        smem += (size_t)P * esz;
+        if (Mp > 1) tiles = 1;  // one workgroup per context owns the row: plain stores, no atomics
+        else {
+            int64_t cap = 1024 / M;
+            if (cap < 1) cap = 1;
+            if (tiles > cap) tiles = cap;
+        }
+    }
     const dim3 grid = grid_xm(tiles, M);
     if (dtype == TNF_F32) {
         auto k = maf_backward_kernel<float>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const float*)z, (const float*)params, (const float*)masks,
                            (const float*)g_zout, (const float*)g_ld, (float*)g_z, (float*)g_params, M, Mp, N, D, L,
-                           U, pstride, gpstride, TS, W);
+                           U, pstride, gpstride, TS, W, lacc, lw, (int)P);
     } else {
         auto k = maf_backward_kernel<double>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const double*)z, (const double*)params,
                            (const double*)masks, (const double*)g_zout, (const double*)g_ld, (double*)g_z,
-                           (double*)g_params, M, Mp, N, D, L, U, pstride, gpstride, TS, W);
+                           (double*)g_params, M, Mp, N, D, L, U, pstride, gpstride, TS, W, lacc, lw, (int)P);
     }
     return check_launch("maf_backward");
 }
