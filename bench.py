@@ -92,6 +92,55 @@ def cpu_baseline(nf, threads):
     }, orc, params, stats
 
 
+def widened_rows(tnf):
+    """Single-GPU extras for the SURVEY 8f rows built after the metric path: not the
+    metric, a few seconds in total."""
+    def timeit(fn, reps):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    res = {}
+    np.random.seed(0)
+    torch.manual_seed(0)
+    nf = tnf.NormFlow(64, True, "coupling", 4, 2, 15)
+    cde = tnf.ConditionalDensityEstimator(nf, 32, [64, 64])
+    M = 1 << 18
+    x = torch.randn(M, 32, device="cuda")
+    z = torch.randn(M, 1, 64, device="cuda")
+
+    def infer():
+        with torch.no_grad():
+            cde.log_prob(z, x)
+
+    def train():
+        cde.zero_grad()
+        (-cde.log_prob(z, x).mean()).backward()
+
+    t = timeit(infer, 5)
+    res["cond_flow_log_prob"] = {"contexts": M, "ms": round(t * 1e3, 3), "value": round(M / t / 1e6, 1),
+                                 "unit": "M contexts/s", "what": "cde.log_prob(z[:, None, :], x), D=64 S=4, param_net "
+                                 "[64,64]: last Linear fused into the flow kernel, params (M, 20464) never materialised"}
+    t = timeit(train, 3)
+    res["cond_flow_train_step"] = {"contexts": M, "ms": round(t * 1e3, 3), "value": round(M / t / 1e6, 2),
+                                   "unit": "M contexts/s", "what": "forward + backward through param_net (fused pair)"}
+    del x, z, cde, nf
+    nf = tnf.NormFlow(16, False, "AR", 1, 2, 32)
+    z = torch.randn(1, 1 << 20, 16, device="cuda")
+    with torch.no_grad():
+        nf(64)
+        t = timeit(lambda: nf.log_prob(z), 10)
+    res["ar_log_prob"] = {"samples": 1 << 20, "ms": round(t * 1e3, 3), "value": round((1 << 20) / t / 1e6, 1),
+                          "unit": "M samples/s", "what": "NormFlow(16, arch_type='AR', num_layers=2, num_units=32).log_prob, "
+                          "one matrix-pipe MAF kernel"}
+    return res
+
+
 def event_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
 
@@ -278,6 +327,9 @@ def main():
             "what": "loss = -mean(log_prob); backward (MFMA backward kernels); "
                     + ("RCCL all-reduce of the flat gradient; " if world > 1 else "") + "Adam step"},
     }
+
+    if world == 1:
+        out["widened"] = widened_rows(tnf)
 
     if not args.no_cpu_baseline and world == 1:
         threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
