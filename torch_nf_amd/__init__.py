@@ -9,7 +9,7 @@ reference's import names so existing `import torch_nf.bijectors` code picks them
 import sys
 
 from . import _lib  # noqa: F401  (fails loudly if libtnf_hip.so is missing)
-from . import bijectors, conditional_density_estimator, density_estimator, error_formatters
+from . import bijectors, conditional_density_estimator, density_estimator, error_formatters, lfi, systems
 from .bijectors import MAF, ToInterval, ToSimplex, Affine, BatchNorm, Bijector, RealNVP
 from .conditional_density_estimator import ConditionalDensityEstimator
 from .density_estimator import DensityEstimator, NormFlow
@@ -23,6 +23,6 @@ def install_as_torch_nf():
     """Alias this package's modules as torch_nf.* (the reference's namespace package)."""
     this = sys.modules[__name__]
     sys.modules.setdefault("torch_nf", this)
-    for name in ("bijectors", "density_estimator", "conditional_density_estimator", "error_formatters"):
+    for name in ("bijectors", "density_estimator", "conditional_density_estimator", "error_formatters", "lfi", "systems"):
         sys.modules["torch_nf." + name] = getattr(this, name)
     return this

@@ -1,0 +1,91 @@
+"""Sequential neural posterior estimation drivers (stand-in for the reference's `torch_nf.lfi`, which is NOT
+part of the snapshot: only the call `train_APT(cnf, mat, x0, M=, M_atom=, R=, num_iters=, verbose=)` and its
+five return values survive -- scripts/lfi_mat.py:44-57, notebooks/LFI_mat_det_trace.ipynb cell 3).  Written
+from the published algorithm: APT / SNPE-C with atomic proposals (Greenberg, Nonnenmacher & Macke, "Automatic
+Posterior Transformation for Likelihood-Free Inference", ICML 2019, eq. 7-8): in round r parameters are drawn
+from the current posterior estimate q(. | x0) (the prior in round 0), simulated, and the conditional density
+estimator is trained on all rounds' pairs with the contrastive loss
+
+    L = - mean_i log [ q(z_i | x_i) / p(z_i)  /  sum_{j in atoms(i)} q(z_j | x_i) / p(z_j) ],
+
+atoms(i) = {i} + (M_atom - 1) other parameters of the batch.  PARITY UNPINNED (no reference outputs exist).
+
+The density evaluations are one `cde.log_prob(z (M, M_atom, D), x (M, D_x))` call per step -- the (contexts x
+atoms) layout of this package's kernels (per-context flow parameters, M_atom samples each).
+"""
+import time
+
+import numpy as np
+import torch
+
+
+def _atom_indices(M, M_atom, device, generator=None):
+    """(M, M_atom) int64: column 0 is the row's own index, the others are M_atom - 1 distinct other rows."""
+    M_atom = min(M_atom, M)
+    # random scores per (row, candidate); the own index is excluded by an infinite score, top-k picks the rest
+    scores = torch.rand((M, M), device=device, generator=generator)
+    scores.fill_diagonal_(2.0)
+    others = torch.topk(scores, M_atom - 1, dim=1, largest=False).indices
+    own = torch.arange(M, device=device)[:, None]
+    return torch.cat((own, others), 1)
+
+
+def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3, num_sims=None, verbose=False):
+    """Train `cde` (a ConditionalDensityEstimator) towards p(z | x0) for the simulator `system`.
+
+    :param system: object with sample_prior(N), log_prior(z), simulate(z) (see systems.Mat).
+    :param x0: (1, D_x) numpy observation.
+    :param M: batch size (contexts per step).  :param M_atom: atoms per context.
+    :param R: rounds.  :param num_iters: optimisation steps per round.
+    :param num_sims: simulations per round (default 10 * M).
+    :return: (cde, losses (R * num_iters), zs [R x (n, D)] posterior samples after each round,
+              log_probs [R x (n,)], it_time seconds per iteration) -- the five values of the reference's call site.
+    """
+    dev = next(cde.param_net.parameters()).device
+    num_sims = num_sims or 10 * M
+    x0_t = torch.as_tensor(np.asarray(x0), dtype=torch.float32, device=dev).reshape(1, -1)
+    opt = torch.optim.Adam(cde.param_net.parameters(), lr=lr)
+    Z = torch.empty((0, system.D), dtype=torch.float32, device=dev)
+    X = torch.empty((0, x0_t.shape[1]), dtype=torch.float32, device=dev)
+    losses, zs, log_probs = [], [], []
+    t_train, n_it = 0.0, 0
+    for r in range(R):
+        if r == 0:
+            z_new = system.sample_prior(num_sims)
+        else:
+            with torch.no_grad():
+                z_s, _ = cde(x0_t, N=num_sims)
+            z_new = z_s[0].detach().cpu().numpy().astype(np.float64)
+        x_new = system.simulate(z_new)
+        ok = np.isfinite(x_new).all(1) & np.isfinite(system.log_prior(z_new))
+        Z = torch.cat((Z, torch.as_tensor(z_new[ok], dtype=torch.float32, device=dev)))
+        X = torch.cat((X, torch.as_tensor(x_new[ok], dtype=torch.float32, device=dev)))
+        n = Z.shape[0]
+        Mb = min(M, n)
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+        t0 = time.perf_counter()
+        for _ in range(num_iters):
+            idx = torch.randint(0, n, (Mb,), device=dev)
+            z_b, x_b = Z[idx], X[idx]
+            atoms = _atom_indices(Mb, M_atom, dev)
+            z_atoms = z_b[atoms]                                  # (Mb, M_atom, D)
+            lp = cde.log_prob(z_atoms, x_b) - system.log_prior(z_atoms)
+            loss = -(lp[:, 0] - torch.logsumexp(lp, dim=1)).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+        t_train += time.perf_counter() - t0
+        n_it += num_iters
+        with torch.no_grad():
+            z_s, lq = cde(x0_t, N=M)
+        zs.append(z_s[0].detach().cpu().numpy())
+        log_probs.append(lq[0].detach().cpu().numpy())
+        if verbose:
+            print("round %d: %d pairs, loss %.4f" % (r, n, float(torch.stack(losses[-max(1, num_iters // 10):]).mean())))
+    losses = torch.stack(losses).cpu().numpy() if losses else np.zeros(0)
+    return cde, losses, zs, log_probs, t_train / max(1, n_it)
+
+
+train_SNPE = train_APT
