@@ -347,6 +347,10 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
     if (!z || !params || !masks || !g_z_out || !g_log_det || !g_z || !g_params)
         return fail(TNF_EINVAL, "tnf_maf_backward: NULL pointer");
     if (N == 0) return TNF_OK;
+    if (dtype == TNF_F32 && !g_force_generic && maf_bwd_mfma_supported(D, L, U))
+        return launch_maf_backward_mfma((const float*)z, (const float*)params, (const float*)masks, (const float*)g_z_out,
+                                        (const float*)g_log_det, (float*)g_z, (float*)g_params, M, M_p, N, D, L, U,
+                                        pstride, gpstride, as_stream(stream));
     return launch_maf_backward(dtype, z, params, masks, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
                                pstride, gpstride, as_stream(stream));
 }
