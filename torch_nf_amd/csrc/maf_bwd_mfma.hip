@@ -35,14 +35,19 @@ struct MafBLayout {  // group numbering shared by the folded image, the transpos
 };
 
 // folded forward image (same maths as build_maf_image of maf_mfma.hip) and the plain transposed image:
-// group (net, out tile, in tile), lane (r, q): W*M [in = 16 it + r][out = 16 ot + 4q + j]
-__device__ void build_maf_bwd_images(float* fimg, float* timg, const float* __restrict__ p, const float* __restrict__ mk,
-                                     MafBLayout wl, int D, int U, int lane) {
+// group (net, out tile, in tile), lane (r, q): W*M [in = 16 it + r][out = 16 ot + 4q + j].
+// The (layer, net, out tile) units are dealt round-robin to the workgroup's `nwaves` waves: with one
+// workgroup per context the build is on the critical path of every context.
+__device__ void build_maf_bwd_images(float* fimg, float* timg, const float* __restrict__ p0, const float* __restrict__ mk0,
+                                     MafBLayout wl, int D, int U, int lane, int wave, int nwaves) {
     const int r = lane & 15, q = lane >> 4;
     float* fw = fimg + lane * 4;
     float* fb = fimg + wl.NWG() * 256 + q * 4;
     float* tw = timg + lane * 4;
     const bool bias_lane = r == 0;
+    int unit = 0;
+    const float* p = p0;
+    const float* mk = mk0;
     for (int layer = 0; layer <= wl.L; ++layer) {
         const int din = layer == 0 ? D : U, dout = layer == wl.L ? D : U;
         const int IT = layer == 0 ? wl.DT : wl.UT, OT = layer == wl.L ? wl.DT : wl.UT;
@@ -52,7 +57,8 @@ __device__ void build_maf_bwd_images(float* fimg, float* timg, const float* __re
             // r = (1 - tanh)/2 (factor -2) and feed a tanh (c) or the outputs (1 for mu, log2 e for alpha)
             const float outsc = layer == wl.L ? (net == 0 ? 1.f : kLog2e) : kTwoLog2e;
             const float wsc = layer == 0 ? outsc : -2.f * outsc;
-            for (int ot = 0; ot < OT; ++ot) {
+            for (int ot = 0; ot < OT; ++ot, ++unit) {
+                if (unit % nwaves != wave) continue;
                 const int g_base = layer == 0 ? wl.g0(net, ot, 0) : (layer == wl.L ? wl.g2(net, ot, 0) : wl.gh(layer - 1, net, ot, 0));
                 float csum = 0.f;
                 for (int it = 0; it < IT; ++it) {
@@ -131,7 +137,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     if (m >= a.M) return;
     const int64_t mp = a.Mp == 1 ? 0 : m;
     for (int i = threadIdx.x; i < NWG * 256; i += 256) gacc[i] = 0.f;
-    if (wave == 0) build_maf_bwd_images(fimg, timg, a.params + mp * a.pstride, a.masks, wl, D, U, lane);
+    build_maf_bwd_images(fimg, timg, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4);
     __syncthreads();
 
     const float* fsrc = fimg + lane * 4;

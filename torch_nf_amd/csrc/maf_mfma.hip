@@ -33,16 +33,19 @@ struct MafLayout {
 
 // packed parameters (bijectors.py:698-740): per layer [W_mu | W_alpha], W row-major [in][out]; masks: one
 // matrix per layer of the same shape.  One full wave builds the image (LDS destination).
+// The (layer, net, out tile) units are dealt round-robin to the workgroup's `nwaves` waves.
 __device__ void build_maf_image(float* img, const float* __restrict__ p, const float* __restrict__ mk, MafLayout wl,
-                                int D, int U, int lane) {
+                                int D, int U, int lane, int wave, int nwaves) {
     const int r = lane & 15, q = lane >> 4;
+    int unit = 0;
     float* wdst = img + lane * 4;
     float* bdst = img + wl.NWG() * 256 + q * 4;
     const bool bias_lane = r == 0;
     {   // layer 0: D -> U, feeds a tanh: scaled by c = 2 log2(e); no bias
         const float* w[2] = {p, p + D * U};
         for (int net = 0; net < 2; ++net)
-            for (int ut = 0; ut < wl.UT; ++ut) {
+            for (int ut = 0; ut < wl.UT; ++ut, ++unit) {
+                if (unit % nwaves != wave) continue;
                 const int u = 16 * ut + r;
                 for (int m = 0; m < wl.DT; ++m) {
                     f4 v;
@@ -61,7 +64,8 @@ __device__ void build_maf_image(float* img, const float* __restrict__ p, const f
     for (int l = 0; l < wl.L - 1; ++l) {  // hidden: U -> U, consume r = (1 - tanh)/2, feed a tanh
         const float* w[2] = {p, p + U * U};
         for (int net = 0; net < 2; ++net)
-            for (int uo = 0; uo < wl.UT; ++uo) {
+            for (int uo = 0; uo < wl.UT; ++uo, ++unit) {
+                if (unit % nwaves != wave) continue;
                 const int o = 16 * uo + r;
                 float csum = 0.f;
                 for (int ui = 0; ui < wl.UT; ++ui) {
@@ -89,7 +93,8 @@ __device__ void build_maf_image(float* img, const float* __restrict__ p, const f
         const float* w[2] = {p, p + U * D};
         for (int net = 0; net < 2; ++net) {
             const float sc = net == 0 ? 1.f : kLog2e;
-            for (int mo = 0; mo < wl.DT; ++mo) {
+            for (int mo = 0; mo < wl.DT; ++mo, ++unit) {
+                if (unit % nwaves != wave) continue;
                 const int o = 16 * mo + r;
                 float csum = 0.f;
                 for (int ui = 0; ui < wl.UT; ++ui) {
@@ -134,7 +139,7 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
         cfold[i] = (has_pre && ok) ? a.pre[mp * a.fold_stride + half * D + f] : (half == 0 ? 1.f : 0.f);
         cfold[2 * DP + i] = (has_post && ok) ? a.post[mp * a.fold_stride + half * D + f] : (half == 0 ? 1.f : 0.f);
     }
-    if (wave == 0) build_maf_image(img, a.params + mp * a.pstride, a.masks, wl, D, U, lane);
+    build_maf_image(img, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4);
     __syncthreads();
 
     const float* wsrc = img + lane * 4;
