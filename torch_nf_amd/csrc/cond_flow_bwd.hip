@@ -435,7 +435,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
 
 // ---------------------------------------------------------------------------
 // Kernel 2: g_W, g_b.  blockIdx.x = job (one (coupling layer, MLP layer, net, 16-output tile) or one
-// Affine 16-feature tile), blockIdx.y = slice of the 32-context chunks.
+// Affine 16-feature tile) x a contiguous slice of the contexts.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cond_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ maxbits) {
     float mx = 0.f;
@@ -454,6 +454,7 @@ struct GwArgs {
     const unsigned* gmaxbits;
     int64_t M, ldh, ldgw;
     CondCfg cfg;
+    int jobs, spp;  // jobs per context slice; 128-context (64 at H = 128) steps per slice
 };
 
 struct GwJob {
@@ -545,7 +546,12 @@ cond_gw_kernel(GwArgs a) {
     __shared__ __attribute__((aligned(16))) u4 hB[(CH / 32) * JT * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const GwJob job = gw_job(a, blockIdx.x);
+    // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own
+    // L2.  All jobs of one context slice are given ids of the same residue mod 8, so the slice's h rows
+    // (a.spp steps, ~1 MB) are fetched into ONE L2 and re-read there by the other jobs.
+    const int xcd = blockIdx.x & 7, tq = blockIdx.x >> 3;
+    const int split = xcd + 8 * (tq / a.jobs);
+    const GwJob job = gw_job(a, tq % a.jobs);
     const int items = job.d_in + 1;
     const int xq = (job.d_in + 3) >> 2;  // float4 per context row of x actually read (rows are padded to 4)
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -629,11 +635,14 @@ cond_gw_kernel(GwArgs a) {
     };
 
     const int64_t nsteps = (a.M + CH - 1) / CH;
-    int64_t st = blockIdx.y;
-    if (st < nsteps) fetch(st * CH);
-    for (; st < nsteps; st += gridDim.y) {
+    int64_t st = (int64_t)split * a.spp;
+    const int64_t st_end = (st + a.spp) < nsteps ? (st + a.spp) : nsteps;
+    const int64_t st_first = st;
+    (void)st_first;  // only the TNF_COND_ABLATE == 3 experiment reads it
+    if (st < st_end) fetch(st * CH);
+    for (; st < st_end; ++st) {
 #if TNF_COND_ABLATE == 3  // timing experiment: stage only the first step
-        if (st == (int64_t)blockIdx.y) {
+        if (st == st_first) {
             commit();
             __syncthreads();
         }
@@ -641,7 +650,7 @@ cond_gw_kernel(GwArgs a) {
         __syncthreads();  // everyone is done reading the previous step
         commit();
         __syncthreads();
-        if (st + gridDim.y < nsteps) fetch((st + gridDim.y) * CH);  // in flight during the MFMAs below
+        if (st + 1 < st_end) fetch((st + 1) * CH);  // in flight during the MFMAs below
 #endif
 #pragma unroll
         for (int sub = 0; sub < CH / 32; ++sub) {
@@ -740,11 +749,17 @@ static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) 
     if (rc) return rc;
     const CondCfg& c = g.cfg;
     const int jobs = c.S * (2 * 2 * (c.L + c.HT) + 2 * c.DT);
-    const int64_t nchunks = (a.M + (KS == 4 ? 63 : 127)) / (KS == 4 ? 64 : 128);
-    int64_t split = 2048 / jobs;
-    if (split < 1) split = 1;
-    if (split > nchunks) split = nchunks;
-    hipLaunchKernelGGL((cond_gw_kernel<DT, KS, 8>), dim3((unsigned)jobs, (unsigned)split), dim3(512), 0, st, g);
+    const int64_t nsteps = (a.M + (KS == 4 ? 63 : 127)) / (KS == 4 ? 64 : 128);
+    // context slices of ~1 MB of h rows (32 steps), at least 8 (one per XCD) when there is enough work
+    int64_t spp = 32;
+    while (spp > 1 && (nsteps + spp - 1) / spp < 16) spp >>= 1;
+    int64_t split = (nsteps + spp - 1) / spp;
+    split = (split + 7) & ~(int64_t)7;
+    GwArgs gg = g;
+    gg.jobs = jobs;
+    gg.spp = (int)spp;
+    if (split * jobs > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "cond_gw: grid too large");
+    hipLaunchKernelGGL((cond_gw_kernel<DT, KS, 8>), dim3((unsigned)(split * jobs)), dim3(512), 0, st, gg);
     return check_launch("cond_gw");
 }
 
