@@ -70,3 +70,52 @@ def test_argument_checks_return_codes_without_launching():
         assert e.code == -1
     assert lib.tnf_flow_workspace_bytes(1, 1 << 20, 64, 4, 2, 15, _lib.FUSE_FLOW) < 1 << 18  # constants + operand images only
     assert lib.tnf_flow_workspace_bytes(1, 1 << 20, 64, 4, 2, 15, _lib.FUSE_LAYER) > (1 << 20) * 64 * 4
+
+
+def test_widened_entries_host_side(oracle):
+    """Host-only behaviour of the entries added for SURVEY 8f: counts, support predicates, sizes and the
+    argument checks that fail before any launch."""
+    from torch_nf_amd import _lib
+
+    lib = _lib.lib
+    dummy = ctypes.c_void_p(256)
+    # MAF
+    for D, L, U in [(4, 2, 20), (64, 2, 64), (5, 1, 15)]:
+        assert lib.tnf_maf_num_params(D, L, U) == oracle.maf_num_params(D, L, U)
+    assert lib.tnf_ar_flow_supported(4, 2, 20) == 1 and lib.tnf_ar_flow_supported(64, 2, 64) == 1
+    assert lib.tnf_ar_flow_supported(64, 5, 64) == 0  # 192 KB of operands do not fit the LDS
+    assert lib.tnf_ar_flow_supported(65, 2, 20) == 0 and lib.tnf_ar_flow_supported(8, 2, 65) == 0
+    assert lib.tnf_ar_flow_workspace_bytes(3, 8) >= 3 * 17 * 4
+    rc = lib.tnf_ar_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, dummy, None, None, 1, 1, 4, 4, 2, 20, 10,
+                                      dummy, 1 << 20, None)
+    assert rc == -1 and b"params row has 10 elements" in lib.tnf_last_error()
+    rc = lib.tnf_ar_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, None, 1, 1, 4, 4, 2, 20, 10000,
+                                      dummy, 1 << 20, None)
+    assert rc == -1 and b"no output requested" in lib.tnf_last_error()
+    rc = lib.tnf_maf(7, dummy, dummy, dummy, dummy, dummy, 1, 1, 4, 4, 2, 20, 1, 10000, None)
+    assert rc == -1 and b"dtype" in lib.tnf_last_error()
+    # support layers
+    assert lib.tnf_to_interval(_lib.F32, dummy, dummy, dummy, dummy, 0, 4, 0, None) == 0  # empty input: no-op
+    assert lib.tnf_to_interval(_lib.F32, None, dummy, dummy, dummy, 5, 4, 0, None) == -1
+    assert lib.tnf_to_simplex(_lib.F64, dummy, dummy, dummy, 3, 0, 4, None) == -1
+    # conditional flow
+    assert lib.tnf_cond_flow_supported(64, 4, 2, 15, 64) == 1 and lib.tnf_cond_flow_supported(32, 1, 5, 16, 128) == 1
+    assert lib.tnf_cond_flow_supported(64, 4, 2, 17, 64) == 0 and lib.tnf_cond_flow_supported(64, 4, 2, 15, 50) == 0
+    assert lib.tnf_cond_flow_supported(16, 4, 2, 15, 64) == 0
+    ws = lib.tnf_cond_flow_workspace_bytes(64, 4, 2, 15, 64)
+    assert 5 << 20 < ws < 6 << 20                      # the 1,328-tile operand image (4,160 B per tile)
+    assert lib.tnf_cond_flow_bwd_workspace_bytes(64, 4, 2, 15, 64) > 2 * ws - (1 << 20)
+    assert lib.tnf_cond_flow_workspace_bytes(64, 4, 2, 15, 50) == _lib.EUNSUPPORTED
+    M = 1000
+    assert lib.tnf_cond_flow_acts_floats(M, 64, 4, 2) == 4 * M * 64 + 8 * M * (3 * 32 + 64)
+    assert lib.tnf_cond_flow_deltas_floats(M, 64, 4, 2) == 8 * M * 64 + 8 * M * (64 + 64)
+    rc = lib.tnf_cond_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, dummy, dummy, None, None, 10, 64, 4, 2, 15,
+                                        64, 62, 64, dummy, ws, None)
+    assert rc == -1 and b"multiples of 4" in lib.tnf_last_error()
+    rc = lib.tnf_cond_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, dummy, dummy, None, None, 10, 64, 4, 2, 15,
+                                        64, 64, 64, dummy, 1024, None)
+    assert rc == -4 and b"workspace" in lib.tnf_last_error()
+    rc = lib.tnf_cond_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, dummy, dummy, None, None, 10, 64, 4, 2, 15,
+                                        64, 64, 64, ctypes.c_void_p(264), ws, None)
+    assert rc == -1 and b"aligned" in lib.tnf_last_error()
+    assert lib.tnf_set_option(_lib.OPT_COND_VARIANT, 0) == 0
