@@ -294,6 +294,11 @@ struct FlowF16Args {
     float* log_prob;
     int64_t Mz, Mp, N, slot;  // slot = floats between consecutive layer images in `images`
     int S;
+    // fold == NULL: the kernel folds BatchNorm / Affine itself in its prologue (one launch less per call)
+    const float* params;
+    const float* bn_mean;
+    const float* bn_alpha;
+    int64_t pstride, stage_stride, affine_off;  // floats per stage; offset of the Affine block inside a stage
 };
 
 template <int H, int NT>
@@ -317,7 +322,9 @@ __device__ __forceinline__ void apply_fold16(const float* fc, int q, f4 (&lo)[NT
     }
 }
 
-template <int H, int L, bool INV, int NT, int NWAVES>
+// SS > 0: the number of stages is fixed at compile time and the layer loop is fully unrolled (every LDS
+// offset of the operand reads becomes an immediate); SS = 0: run-time a.S.
+template <int H, int L, bool INV, int NT, int NWAVES, int SS = 0>
 __global__ void __launch_bounds__(NWAVES * 64)
 flow_fused_f16_kernel(FlowF16Args a) {
     constexpr int D = 2 * H;
@@ -328,6 +335,7 @@ flow_fused_f16_kernel(FlowF16Args a) {
     float* img = lds;
     float* fold = lds + nl * Img::FLOATS;
     int* qhead = reinterpret_cast<int*>(fold + nl * 2 * D);
+    float* red = fold + nl * 2 * D + 4;  // [NWAVES] partial log-det constants
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -341,8 +349,41 @@ flow_fused_f16_kernel(FlowF16Args a) {
             f4* idst = reinterpret_cast<f4*>(img + c * Img::FLOATS);
             for (int i = threadIdx.x; i < Img::FLOATS / 4; i += NWAVES * 64) idst[i] = isrc[i];
         }
-        const float* fsrc = a.fold + mp * (int64_t)nl * 2 * D;
-        for (int i = threadIdx.x; i < nl * 2 * D; i += NWAVES * 64) fold[i] = fsrc[i];
+        if (a.fold) {
+            const float* fsrc = a.fold + mp * (int64_t)nl * 2 * D;
+            for (int i = threadIdx.x; i < nl * 2 * D; i += NWAVES * 64) fold[i] = fsrc[i];
+        } else {
+            // the arithmetic of flow_fold_kernel (coupling_mfma.hip): per layer c and feature d
+            //   inverse: A = alpha_bn / e^a, B = mean_bn - shift A;  forward: A = e^a / alpha_bn, B = shift - mean_bn A
+            // (a, shift: the Affine in front of odd layers), ldc = sum a - sum log alpha_bn
+            const float* prow = a.params + mp * a.pstride;
+            float acc = 0.f;
+            for (int i = threadIdx.x; i < nl * D; i += NWAVES * 64) {
+                const int c = i / D, d = i - c * D;
+                const float alpha = a.bn_alpha[c * D + d], mu = a.bn_mean[c * D + d];
+                acc -= logf(alpha);
+                float ea = 1.f, shift = 0.f;
+                if (c & 1) {
+                    const float* ap = prow + (c >> 1) * a.stage_stride + a.affine_off;
+                    const float av = ap[d];
+                    acc += av;
+                    ea = expf(av);
+                    shift = ap[D + d];
+                }
+                float A, B;
+                if (INV) {
+                    A = alpha / ea;
+                    B = mu - shift * A;
+                } else {
+                    A = ea / alpha;
+                    B = shift - mu * A;
+                }
+                fold[c * 2 * D + d] = A;
+                fold[c * 2 * D + D + d] = B;
+            }
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0) red[wave] = acc;
+        }
         if (threadIdx.x == 0) *qhead = NWAVES;
     }
     __syncthreads();
@@ -351,7 +392,12 @@ flow_fused_f16_kernel(FlowF16Args a) {
     float* zo = a.z_out ? a.z_out + m * a.N * D : nullptr;
     float* sldo = a.sum_log_det ? a.sum_log_det + m * a.N : nullptr;
     float* lpo = a.log_prob ? a.log_prob + m * a.N : nullptr;
-    const float ldc = a.ldc[mp];
+    float ldc = 0.f;
+    if (a.fold) ldc = a.ldc[mp];
+    else {
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) ldc += red[w];
+    }
 
     const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
     const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
@@ -402,22 +448,29 @@ flow_fused_f16_kernel(FlowF16Args a) {
                 }
             }
         }
-        if (INV) {
-            for (int st = a.S - 1; st >= 0; --st) {
-                const int c1 = 2 * st + 1, c0 = 2 * st;
-                apply_fold16<H, NT>(fold + c1 * 2 * D, q, lo, hi);
-                coupling_tile_f16<H, L, true, NT>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
-                apply_fold16<H, NT>(fold + c0 * 2 * D, q, lo, hi);
-                coupling_tile_f16<H, L, true, NT>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
+        auto stage_inv = [&](int st) {
+            const int c1 = 2 * st + 1, c0 = 2 * st;
+            apply_fold16<H, NT>(fold + c1 * 2 * D, q, lo, hi);
+            coupling_tile_f16<H, L, true, NT>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
+            apply_fold16<H, NT>(fold + c0 * 2 * D, q, lo, hi);
+            coupling_tile_f16<H, L, true, NT>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
+        };
+        auto stage_fwd = [&](int st) {
+            const int c0 = 2 * st, c1 = 2 * st + 1;
+            coupling_tile_f16<H, L, false, NT>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
+            apply_fold16<H, NT>(fold + c0 * 2 * D, q, lo, hi);
+            coupling_tile_f16<H, L, false, NT>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
+            apply_fold16<H, NT>(fold + c1 * 2 * D, q, lo, hi);
+        };
+        if constexpr (SS > 0) {
+#pragma unroll
+            for (int i = 0; i < SS; ++i) {
+                if (INV) stage_inv(SS - 1 - i); else stage_fwd(i);
             }
+        } else if (INV) {
+            for (int st = a.S - 1; st >= 0; --st) stage_inv(st);
         } else {
-            for (int st = 0; st < a.S; ++st) {
-                const int c0 = 2 * st, c1 = 2 * st + 1;
-                coupling_tile_f16<H, L, false, NT>(img + c0 * Img::FLOATS, lane, lo, hi, ssum);
-                apply_fold16<H, NT>(fold + c0 * 2 * D, q, lo, hi);
-                coupling_tile_f16<H, L, false, NT>(img + c1 * Img::FLOATS, lane, hi, lo, ssum);
-                apply_fold16<H, NT>(fold + c1 * 2 * D, q, lo, hi);
-            }
+            for (int st = 0; st < a.S; ++st) stage_fwd(st);
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -473,10 +526,10 @@ int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D
     return check_launch("flow_images_f16");
 }
 
-template <int H, int L, bool INV, int NT, int NW>
+template <int H, int L, bool INV, int NT, int NW, int SS = 0>
 static int launch16_t(const FlowF16Args& a, int64_t M, hipStream_t st) {
-    const size_t smem = (size_t)2 * a.S * (F16Image<H, L>::FLOATS + 2 * 2 * H) * sizeof(float) + 16;
-    auto kern = flow_fused_f16_kernel<H, L, INV, NT, NW>;
+    const size_t smem = (size_t)2 * a.S * (F16Image<H, L>::FLOATS + 2 * 2 * H) * sizeof(float) + 16 + NW * sizeof(float);
+    auto kern = flow_fused_f16_kernel<H, L, INV, NT, NW, SS>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_fused_f16: cannot reserve %zu B of LDS", smem);
     const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
@@ -493,7 +546,10 @@ static int launch16_v(const FlowF16Args& a, int64_t M, int variant, hipStream_t 
         if (variant == 11) return launch16_t<H, L, INV, 1, 8>(a, M, st);
         if (variant == 12) return launch16_t<H, L, INV, 1, 16>(a, M, st);
         if (variant == 13) return launch16_t<H, L, INV, 2, 16>(a, M, st);
+        if (variant == 14) return launch16_t<H, L, INV, 2, 8>(a, M, st);  // run-time stage loop
     }
+    // the reference's usual depth (num_stages = 4): layer loop fully unrolled, 3 % faster at D = 64
+    if (a.S == 4) return launch16_t<H, L, INV, 2, 8, 4>(a, M, st);
     return launch16_t<H, L, INV, 2, 8>(a, M, st);
 }
 
@@ -508,11 +564,14 @@ static int launch16_h(const FlowF16Args& a, int L, int inverse, int64_t M, int v
 
 int launch_flow_fused_f16(const float* z, const float* images, const float* fold, const float* ldc,
                           float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
-                          int64_t N, int D, int S, int L, int U, int inverse, int variant, hipStream_t st) {
-    (void)U;
+                          int64_t N, int D, int S, int L, int U, int inverse, int variant, hipStream_t st,
+                          const float* params, int64_t pstride, const float* bn_mean, const float* bn_alpha) {
     const int64_t M = Mz > Mp ? Mz : Mp;
     if (N <= 0) return TNF_OK;
-    FlowF16Args a{z, images, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, mfma_image_floats(D, 3), S};
+    if (!fold && (!params || !bn_mean || !bn_alpha)) return fail(TNF_EINVAL, "flow_fused_f16: nothing to fold from");
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    FlowF16Args a{z, images, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, mfma_image_floats(D, 3), S,
+                  params, bn_mean, bn_alpha, pstride, fl.stage, fl.p_up + fl.p_low};
     int rc = (D == 64) ? launch16_h<32>(a, L, inverse, M, variant, st) : launch16_h<16>(a, L, inverse, M, variant, st);
     if (rc != TNF_OK) return rc;
     return check_launch("flow_fused_f16");
