@@ -265,7 +265,7 @@ def main():
     total_samples = N_PER_GPU * world * args.steps
     value = total_samples / wall_max / 1e6
     flops = flop_per_sample(D, S, L, U)
-    ev_mean = float(np.mean(ev))  # ms per call on the launch stream: the dominant kernel + the 8-block operand-image kernel in front of it
+    ev_mean = float(np.mean(ev))  # ms per call on the launch stream = the one kernel of the call (it builds its operands in its prologue)
     if fused:
         achieved = N_PER_GPU * flops / (ev_mean * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "flow_fused_f16_kernel<32,2,inverse,2,8>", "achieved": round(achieved, 3),

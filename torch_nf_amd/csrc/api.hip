@@ -576,12 +576,9 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
     const bool narrow = mfma_supported(D, L, U);
     const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
     const bool f16 = use_fused && g_flow_variant >= 10;  // builds its own (split-f16) images
-    if (f16) {  // two launches: split-f16 operand images, then the flow (which folds BN / Affine itself)
-        rc = launch_flow_images_f16(params, images, M_p, D, S, L, U, pstride, st);
-        if (rc) return rc;
-        return launch_flow_fused_f16(z, images, nullptr, nullptr, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U,
+    if (f16)  // ONE launch: the flow kernel builds its split-f16 operands and folds BN / Affine in its prologue
+        return launch_flow_fused_f16(z, nullptr, nullptr, nullptr, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U,
                                      1, g_flow_variant, st, params, pstride, bn_mean, bn_alpha);
-    }
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride, 1, st);
     if (rc) return rc;
     if (!narrow) {
@@ -794,12 +791,9 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
     const bool narrow = mfma_supported(D, L, U);
     const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
     const bool f16 = use_fused && g_flow_variant >= 10;
-    if (f16) {
-        rc = launch_flow_images_f16(params, images, M_p, D, S, L, U, pstride, st);
-        if (rc) return rc;
-        return launch_flow_fused_f16(omega, images, nullptr, nullptr, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L,
+    if (f16)
+        return launch_flow_fused_f16(omega, nullptr, nullptr, nullptr, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L,
                                      U, 0, g_flow_variant, st, params, pstride, bn_mean, bn_alpha);
-    }
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride, 0, st);
     if (rc) return rc;
     if (!narrow) {

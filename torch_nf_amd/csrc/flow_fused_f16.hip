@@ -95,22 +95,14 @@ static_assert(F16Image<16, 3>::FLOATS <= LdsLayerImage<16, 3>::FLOATS, "f16 imag
 // Prep: one wave per (layer, context) folds + gathers the fp32 operands (load_layer_w),
 // splits them and writes the f16 image.
 // ---------------------------------------------------------------------------
+// one wave: gather + fold + split the operands of the coupling layer whose parameters start at `p` and
+// write its image to `img` (global memory in the prep kernel, LDS when the flow kernel builds its own)
 template <int H, int L>
-__global__ void __launch_bounds__(64)
-flow_images_f16_kernel(const float* __restrict__ params, float* __restrict__ images, int S, int U,
-                       int64_t pstride, int64_t image_floats, int64_t Mp) {
-    constexpr int D = 2 * H;
+__device__ __forceinline__ void build_f16_image(float* img, const float* __restrict__ p, int U, int lane) {
     typedef F16Image<H, L> Img;
     constexpr int HT = Img::HT;
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x;
-    const int64_t m = grid_m();
-    if (m >= Mp) return;
-    const int64_t pc = coupling_num_params(D, L, U, 1);
-    const int64_t stage = 2 * pc + 2 * D;
     LayerW<H, L> w;
-    load_layer_w<H, L>(w, params + m * pstride + (c >> 1) * stage + (c & 1) * pc, U, lane);
-    float* img = images + (m * 2 * S + c) * image_floats;
+    load_layer_w<H, L>(w, p, U, lane);
     u4* grp = reinterpret_cast<u4*>(img) + lane;  // group g at grp[g * 64]
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
@@ -152,6 +144,20 @@ flow_images_f16_kernel(const float* __restrict__ params, float* __restrict__ ima
             for (int mo = 0; mo < HT; ++mo) *reinterpret_cast<f4*>(bl + Img::b_b2(net, mo) * 16) = w.b2[net][mo];
         }
     }
+}
+
+template <int H, int L>
+__global__ void __launch_bounds__(64)
+flow_images_f16_kernel(const float* __restrict__ params, float* __restrict__ images, int S, int U,
+                       int64_t pstride, int64_t image_floats, int64_t Mp) {
+    constexpr int D = 2 * H;
+    const int c = blockIdx.x;
+    const int64_t m = grid_m();
+    if (m >= Mp) return;
+    const int64_t pc = coupling_num_params(D, L, U, 1);
+    const int64_t stage = 2 * pc + 2 * D;
+    build_f16_image<H, L>(images + (m * 2 * S + c) * image_floats, params + m * pstride + (c >> 1) * stage + (c & 1) * pc,
+                          U, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -299,6 +305,8 @@ struct FlowF16Args {
     const float* bn_mean;
     const float* bn_alpha;
     int64_t pstride, stage_stride, affine_off;  // floats per stage; offset of the Affine block inside a stage
+    int64_t low_off;                            // offset of RealNVP(lower) inside a stage
+    int U;
 };
 
 template <int H, int NT>
@@ -344,10 +352,16 @@ flow_fused_f16_kernel(FlowF16Args a) {
     if (m >= (a.Mz > a.Mp ? a.Mz : a.Mp)) return;
     const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
     {
-        for (int c = 0; c < nl; ++c) {
-            const f4* isrc = reinterpret_cast<const f4*>(a.images + (mp * nl + c) * a.slot);
-            f4* idst = reinterpret_cast<f4*>(img + c * Img::FLOATS);
-            for (int i = threadIdx.x; i < Img::FLOATS / 4; i += NWAVES * 64) idst[i] = isrc[i];
+        if (a.images) {
+            for (int c = 0; c < nl; ++c) {
+                const f4* isrc = reinterpret_cast<const f4*>(a.images + (mp * nl + c) * a.slot);
+                f4* idst = reinterpret_cast<f4*>(img + c * Img::FLOATS);
+                for (int i = threadIdx.x; i < Img::FLOATS / 4; i += NWAVES * 64) idst[i] = isrc[i];
+            }
+        } else {  // no prepared images: the workgroup's waves build the layers' operands straight into LDS
+            for (int c = wave; c < nl; c += NWAVES)
+                build_f16_image<H, L>(img + c * Img::FLOATS,
+                                      a.params + mp * a.pstride + (c >> 1) * a.stage_stride + (c & 1) * a.low_off, a.U, lane);
         }
         if (a.fold) {
             const float* fsrc = a.fold + mp * (int64_t)nl * 2 * D;
@@ -568,10 +582,11 @@ int launch_flow_fused_f16(const float* z, const float* images, const float* fold
                           const float* params, int64_t pstride, const float* bn_mean, const float* bn_alpha) {
     const int64_t M = Mz > Mp ? Mz : Mp;
     if (N <= 0) return TNF_OK;
-    if (!fold && (!params || !bn_mean || !bn_alpha)) return fail(TNF_EINVAL, "flow_fused_f16: nothing to fold from");
+    if ((!fold || !images) && (!params || !bn_mean || !bn_alpha))
+        return fail(TNF_EINVAL, "flow_fused_f16: nothing to build the operands from");
     const FlowLayout fl = flow_layout(D, S, L, U);
     FlowF16Args a{z, images, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, mfma_image_floats(D, 3), S,
-                  params, bn_mean, bn_alpha, pstride, fl.stage, fl.p_up + fl.p_low};
+                  params, bn_mean, bn_alpha, pstride, fl.stage, fl.p_up + fl.p_low, fl.p_up, U};
     int rc = (D == 64) ? launch16_h<32>(a, L, inverse, M, variant, st) : launch16_h<16>(a, L, inverse, M, variant, st);
     if (rc != TNF_OK) return rc;
     return check_launch("flow_fused_f16");
