@@ -288,3 +288,33 @@ def test_shard_bounds():
             assert max(sizes) - min(sizes) <= 1
     with raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+def test_lfi_host_pieces():
+    """CPU-only parts of the LFI stand-ins (torch_nf_amd/systems.py, lfi.py): the Mat simulator, its uniform prior
+    and the atom index sampler of the APT loss."""
+    from torch_nf_amd.lfi import _atom_indices
+    from torch_nf_amd.systems import Mat
+
+    mat = Mat(3)
+    assert mat.D == 6 and mat.D_x == 2 and mat.lb.shape == (6,) and (mat.lb < mat.ub).all()
+    z = np.array([[1.0, 0.5, 0.0, 2.0, 0.25, 3.0]])  # upper triangle, row-wise
+    A = mat.matrices(z)[0]
+    assert np.allclose(A, A.T) and np.allclose(np.diag(A), [1.0, 2.0, 3.0]) and A[0, 1] == 0.5 and A[1, 2] == 0.25
+    x = mat.simulate(z)
+    assert x.shape == (1, 2) and np.isclose(x[0, 0], np.linalg.det(A)) and np.isclose(x[0, 1], 6.0)
+    np.random.seed(0)
+    zs = mat.sample_prior(100)
+    assert zs.shape == (100, 6) and (zs >= mat.lb).all() and (zs <= mat.ub).all()
+    lp = mat.log_prior(zs)
+    assert np.allclose(lp, -6 * np.log(4.0))
+    assert np.isneginf(mat.log_prior(np.full((1, 6), 5.0)))[0]
+    lpt = mat.log_prior(torch.tensor(zs, dtype=torch.float32).reshape(10, 10, 6))
+    assert lpt.shape == (10, 10) and torch.allclose(lpt, torch.full((10, 10), float(-6 * np.log(4.0))))
+    with raises(ValueError):
+        Mat(0)
+    torch.manual_seed(0)
+    atoms = _atom_indices(40, 8, torch.device("cpu"))
+    assert atoms.shape == (40, 8) and bool((atoms[:, 0] == torch.arange(40)).all())
+    assert all(len(set(r.tolist())) == 8 for r in atoms)
+    assert _atom_indices(5, 100, torch.device("cpu")).shape == (5, 5)  # never more atoms than batch rows
