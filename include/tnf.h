@@ -257,15 +257,21 @@ int tnf_to_simplex_backward(int32_t dtype, const void* z, const void* g_z_out, c
  * (log_prob: Affine^-1, BN^-1, MAF^-1, base density; :390-416) or behind (frozen forward: MAF, BN, Affine;
  * :374-388 with use_last=True) the MAF kernel.  params rows: [MAF | alpha (D) | shift (D)]; bn_mean /
  * bn_alpha (D).  tnf_ar_flow_log_prob_f32: any of log_prob, z0, sum_log_det may be NULL (not all).
+ * interval_consts: NULL, or the (7, D) constant block of a ToInterval support layer (see tnf_to_interval)
+ * appended to the stack (density_estimator.py:278-282): its inverse then runs in the kernel's load stage
+ * (log_prob) / its forward map in the store stage (forward), with hardware transcendentals, and its
+ * log-det is included in sum_log_det / log_prob.
  * Supported (tnf_ar_flow_supported): D <= 64, num_units <= 64, num_layers <= 5. */
 int tnf_ar_flow_supported(int32_t D, int32_t num_layers, int32_t num_units);
 int64_t tnf_ar_flow_workspace_bytes(int64_t M_p, int32_t D);
 int tnf_ar_flow_log_prob_f32(const float* z, const float* params, const float* masks, const float* bn_mean,
-                             const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, int64_t M_z,
+                             const float* bn_alpha, const float* interval_consts, float* log_prob, float* z0,
+                             float* sum_log_det, int64_t M_z,
                              int64_t M_p, int64_t N, int32_t D, int32_t num_layers, int32_t num_units,
                              int64_t params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 int tnf_ar_flow_forward_f32(const float* omega, const float* params, const float* masks, const float* bn_mean,
-                            const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z, int64_t M_p,
+                            const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
+                            int64_t M_z, int64_t M_p,
                             int64_t N, int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                             void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -86,10 +86,10 @@ def test_widened_entries_host_side(oracle):
     assert lib.tnf_ar_flow_supported(64, 5, 64) == 0  # 192 KB of operands do not fit the LDS
     assert lib.tnf_ar_flow_supported(65, 2, 20) == 0 and lib.tnf_ar_flow_supported(8, 2, 65) == 0
     assert lib.tnf_ar_flow_workspace_bytes(3, 8) >= 3 * 17 * 4
-    rc = lib.tnf_ar_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, dummy, None, None, 1, 1, 4, 4, 2, 20, 10,
+    rc = lib.tnf_ar_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, dummy, None, None, 1, 1, 4, 4, 2, 20, 10,
                                       dummy, 1 << 20, None)
     assert rc == -1 and b"params row has 10 elements" in lib.tnf_last_error()
-    rc = lib.tnf_ar_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, None, 1, 1, 4, 4, 2, 20, 10000,
+    rc = lib.tnf_ar_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, None, None, 1, 1, 4, 4, 2, 20, 10000,
                                       dummy, 1 << 20, None)
     assert rc == -1 and b"no output requested" in lib.tnf_last_error()
     rc = lib.tnf_maf(7, dummy, dummy, dummy, dummy, dummy, 1, 1, 4, 4, 2, 20, 1, 10000, None)

@@ -134,3 +134,33 @@ def test_support_edge_cases(tnf):
     z, ld = iv(torch.tensor([[[30.0, 30.0, 30.0], [-30.0, -30.0, -30.0]]], device="cuda"))
     assert torch.isfinite(z).all() and torch.isfinite(ld).all()
     assert float(z[0, 0, 2]) == 30.0
+
+
+def test_fused_support_ar(tnf):
+    """NormFlow('AR', support_layer=ToInterval): log_prob and the frozen forward as ONE kernel (ToInterval in the
+    kernel's load / store stage, hardware transcendentals) against the composition of the standalone kernels
+    (libm) of the same package."""
+    for D, L, U, M, N in [(6, 2, 15, 1, 700), (21, 2, 42, 3, 130), (4, 1, 20, 2, 64)]:
+        np.random.seed(D)
+        torch.manual_seed(D)
+        lb = np.where(np.arange(D) % 3 == 0, -np.inf, -2.0 - np.arange(D) / 8.0)
+        ub = np.where(np.arange(D) % 3 == 1, np.inf, 2.5 + np.arange(D) / 4.0)
+        nf = tnf.NormFlow(D, True, "AR", 1, L, U, tnf.ToInterval(D, lb, ub))
+        g = torch.Generator().manual_seed(D)
+        nf.bijectors[1].set_last_stats(torch.randn(D, generator=g) * 0.1, torch.rand(D, generator=g) * 0.5 + 0.75)
+        # moderate magnitudes: where tanh saturates in float32 (|z| > 8) log(1 - tanh^2 + eps) is -16 or -28
+        # depending on the last ulp of tanh, in the reference as much as here
+        params = (torch.randn(M, nf.D_params, generator=g) * 0.1).cuda()
+        omega = torch.randn(M, N, D, generator=g).clamp_(-2.5, 2.5).cuda()
+        with torch.no_grad():
+            z, lq = nf._forward_from(omega, params, freeze_bn=True)          # fused: MAF, BN, Affine, ToInterval
+            lp = nf.log_prob(z, params)                                      # fused: ToInterval^-1, ..., base density
+        p2 = params.clone().requires_grad_()                                 # autograd mode -> per-bijector kernels
+        z2, lq2 = nf._forward_from(omega, p2, freeze_bn=True)
+        lp2 = nf.log_prob(z2.detach(), p2)
+        tol = 2e-4 * max(1, D // 8)
+        torch.testing.assert_close(z, z2.detach(), rtol=tol, atol=tol)
+        torch.testing.assert_close(lq, lq2.detach(), rtol=1e-5, atol=10 * tol)
+        torch.testing.assert_close(lp, lp2.detach(), rtol=1e-4, atol=20 * tol)
+        # forward / log_prob consistency through the support layer
+        assert float((lq.float() - lp).abs().max()) < 5e-2

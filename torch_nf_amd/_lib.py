@@ -55,9 +55,9 @@ SIGNATURES = {
                                                        _i64, _vp]),
     "tnf_ar_flow_supported": (ctypes.c_int, [_i32, _i32, _i32]),
     "tnf_ar_flow_workspace_bytes": (_i64, [_i64, _i32]),
-    "tnf_ar_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+    "tnf_ar_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                                  _i32, _i64, _vp, _i64, _vp]),
-    "tnf_ar_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32,
+    "tnf_ar_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32,
                                                 _i64, _vp, _i64, _vp]),
     "tnf_to_interval": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_to_interval_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),

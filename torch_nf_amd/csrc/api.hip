@@ -289,7 +289,8 @@ int64_t tnf_ar_flow_workspace_bytes(int64_t M_p, int32_t D) {
 }
 
 static int ar_flow_run(const char* fn, int inverse, const float* z, const float* params, const float* masks,
-                       const float* bn_mean, const float* bn_alpha, float* z_out, float* sum_log_det, float* log_prob,
+                       const float* bn_mean, const float* bn_alpha, const float* interval_consts, float* z_out,
+                       float* sum_log_det, float* log_prob,
                        int64_t M_z, int64_t M_p, int64_t N, int D, int L, int U, int64_t pstride, void* workspace,
                        int64_t workspace_bytes, void* stream) {
     int rc = check_mnd(fn, M_z, M_p, N, D);
@@ -313,25 +314,30 @@ static int ar_flow_run(const char* fn, int inverse, const float* z, const float*
     if (inverse) a.pre = fold; else a.post = fold;
     a.fold_stride = 2 * (int64_t)D;
     a.ld_out = sum_log_det; a.ld_sign = 1.f; a.ldc = ldc; a.add_ldc = 1; a.log_prob = log_prob;
+    a.iv = interval_consts;
     a.Mz = M_z; a.Mp = M_p; a.N = N; a.D = D; a.L = L; a.U = U; a.inverse = inverse;
     return launch_maf_mfma(a, as_stream(stream));
 }
 
 int tnf_ar_flow_log_prob_f32(const float* z, const float* params, const float* masks, const float* bn_mean,
-                             const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det, int64_t M_z,
+                             const float* bn_alpha, const float* interval_consts, float* log_prob, float* z0,
+                             float* sum_log_det, int64_t M_z,
                              int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U, int64_t pstride, void* workspace,
                              int64_t workspace_bytes, void* stream) {
     if (!log_prob && !z0 && !sum_log_det) return fail(TNF_EINVAL, "tnf_ar_flow_log_prob_f32: no output requested");
-    return ar_flow_run("tnf_ar_flow_log_prob_f32", 1, z, params, masks, bn_mean, bn_alpha, z0, sum_log_det, log_prob, M_z,
+    return ar_flow_run("tnf_ar_flow_log_prob_f32", 1, z, params, masks, bn_mean, bn_alpha, interval_consts, z0, sum_log_det,
+                       log_prob, M_z,
                        M_p, N, D, L, U, pstride, workspace, workspace_bytes, stream);
 }
 
 int tnf_ar_flow_forward_f32(const float* omega, const float* params, const float* masks, const float* bn_mean,
-                            const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z, int64_t M_p, int64_t N,
+                            const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
+                            int64_t M_z, int64_t M_p, int64_t N,
                             int32_t D, int32_t L, int32_t U, int64_t pstride, void* workspace, int64_t workspace_bytes,
                             void* stream) {
     if (!z_out || !sum_log_det) return fail(TNF_EINVAL, "tnf_ar_flow_forward_f32: NULL pointer");
-    return ar_flow_run("tnf_ar_flow_forward_f32", 0, omega, params, masks, bn_mean, bn_alpha, z_out, sum_log_det, nullptr,
+    return ar_flow_run("tnf_ar_flow_forward_f32", 0, omega, params, masks, bn_mean, bn_alpha, interval_consts, z_out,
+                       sum_log_det, nullptr,
                        M_z, M_p, N, D, L, U, pstride, workspace, workspace_bytes, stream);
 }
 

@@ -12,6 +12,7 @@
 // folded Affine^-1 . BatchNorm^-1 of NormFlow('AR').log_prob) and after (`post`: BatchNorm . Affine of the
 // frozen forward), and the base-density epilogue, make NormFlow('AR') one kernel per call.
 #include "mfma_tile.h"
+#include "support_math.h"
 #include "tnf_common.h"
 
 namespace tnf {
@@ -125,7 +126,8 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = a.D, U = a.U;
     float* cfold = lds;           // pre A|B, post A|B (4 * 16 * DT floats)
-    float* img = lds + 4 * 16 * DT;
+    float* ivc = lds + 4 * 16 * DT;  // ToInterval constants, 7 rows of 16 * DT (flags 0 = identity when absent)
+    float* img = ivc + 7 * 16 * DT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     const int64_t m = grid_m();
@@ -139,6 +141,11 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
         cfold[i] = (has_pre && ok) ? a.pre[mp * a.fold_stride + half * D + f] : (half == 0 ? 1.f : 0.f);
         cfold[2 * DP + i] = (has_post && ok) ? a.post[mp * a.fold_stride + half * D + f] : (half == 0 ? 1.f : 0.f);
     }
+    for (int i = threadIdx.x; i < 7 * DP; i += 256) {
+        const int row = i / DP, f = i - row * DP;
+        ivc[i] = (a.iv && f < D) ? a.iv[row * D + f] : 0.f;
+    }
+    const bool has_iv = a.iv != nullptr;
     build_maf_image(img, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4);
     __syncthreads();
 
@@ -217,6 +224,7 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
         const int64_t row = tile * 16 + s;
         const bool row_ok = row < a.N;
         const float* zr = zb + (row_ok ? row : a.N - 1) * D;
+        float sup_ld = 0.f;  // log-det of the fused support layer (this lane's features)
         f4 x[DT];
 #pragma unroll
         for (int mm = 0; mm < DT; ++mm) {
@@ -226,6 +234,15 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) x[mm][j] = ld_sel(zr, f0 + j, f0 + j < D);
+            }
+            if (INV && has_iv) {  // support layer first in the inverse pass: ToInterval^-1 on the raw input
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float o, l;
+                    interval_fast<true>(x[mm][j], ivc, DP, f0 + j, o, l);
+                    x[mm][j] = o;
+                    sup_ld += l;
+                }
             }
             const f4 A = *reinterpret_cast<const f4*>(cfold + f0), B = *reinterpret_cast<const f4*>(cfold + DP + f0);
             x[mm] = x[mm] * A + B;  // padded features: 0 * 1 + 0
@@ -263,8 +280,17 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
             const int f0 = 16 * mm + 4 * q;
             const f4 A = *reinterpret_cast<const f4*>(cfold + 2 * DP + f0), B = *reinterpret_cast<const f4*>(cfold + 3 * DP + f0);
             y[mm] = y[mm] * A + B;
+            if (!INV && has_iv) {  // support layer last in the forward pass
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float o, l;
+                    interval_fast<false>(y[mm][j], ivc, DP, f0 + j, o, l);
+                    y[mm][j] = o;
+                    sup_ld += l;
+                }
+            }
         }
-        float ld_tot = a.ld_sign * reduce_q(ssum) * kLn2;
+        float ld_tot = a.ld_sign * reduce_q(ssum) * kLn2 + reduce_q(sup_ld);
         if (a.add_ldc) ld_tot += ldc;
         if (lpo) {
             float sq = 0.f;
@@ -341,7 +367,7 @@ static MafLayout maf_layout(int D, int L, int U) {
 bool maf_mfma_supported(int D, int L, int U) {
     if (D < 1 || D > 64 || L < 1 || L > 5 || U < 1 || U > 64) return false;
     const MafLayout wl = maf_layout(D, L, U);
-    return (size_t)(4 * 16 * wl.DT + wl.floats()) * sizeof(float) <= 150 * 1024;
+    return (size_t)(11 * 16 * wl.DT + wl.floats()) * sizeof(float) <= 150 * 1024;
 }
 
 template <int DT, int UT>
@@ -380,7 +406,7 @@ int launch_maf_mfma(const MafArgs& a, hipStream_t st) {
     const int64_t M = a.Mz > a.Mp ? a.Mz : a.Mp;
     if (a.N <= 0) return TNF_OK;
     const MafLayout wl = maf_layout(a.D, a.L, a.U);
-    const size_t smem = (size_t)(4 * 16 * wl.DT + wl.floats()) * sizeof(float);
+    const size_t smem = (size_t)(11 * 16 * wl.DT + wl.floats()) * sizeof(float);
     const int64_t ntiles = (a.N + 15) / 16;
     int64_t bx = (ntiles + 3) / 4;
     int64_t cap = 2048 / M;

@@ -210,6 +210,7 @@ struct MafArgs {
     const float* ldc;
     int add_ldc;
     float* log_prob;     // (M, N) or NULL: -|z'|^2/2 - D log sqrt(2 pi) - (ld_sign * sum(alpha) + ldc[m])
+    const float* iv;     // ToInterval constants (7, D) of a fused support layer, or NULL
     int64_t Mz, Mp, N;
     int D, L, U, inverse;
 };

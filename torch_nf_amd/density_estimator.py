@@ -186,6 +186,14 @@ class NormFlow(DensityEstimator):
         return (maf._masks_for(torch.float32), bn.get_last_mean().detach(), bn.get_last_alpha().detach(), self.D,
                 self.num_layers, self.num_units)
 
+    def _fused_support(self):
+        """The (7, D) device constants of a ToInterval support layer that the one-kernel paths evaluate in
+        their load / store stage, or None (no support layer).  Other support layers are not fused."""
+        if self._n_core == len(self.bijectors):
+            return None
+        sup = self.bijectors[-1]
+        return sup._device_consts() if sup.name == "ToInterval" else False
+
     def _fused_ok(self, z, params):
         """One-call fused path: coupling stack, float32, no autograd, MFMA-covered shape."""
         if self.arch_type != "coupling":
@@ -243,9 +251,12 @@ class NormFlow(DensityEstimator):
             log_q = ops.base_log_density_f64(omega64)
         p_dev = params if params.device == dev else params.to(dev)
 
-        if freeze_bn and self._ar_fused_ok(z, p_dev):
-            z, sld = ops.ar_flow_forward_raw(z, p_dev, *self._ar_args())
+        sup = self._fused_support()
+        support_done = False
+        if freeze_bn and self._ar_fused_ok(z, p_dev) and sup is not False:
+            z, sld = ops.ar_flow_forward_raw(z, p_dev, *self._ar_args(), interval_consts=sup)
             log_q = log_q - sld
+            support_done = True
         elif freeze_bn and self._fused_ok(z, p_dev):
             mean, alpha = self._bn_stats(dev)
             z, sld = ops.flow_forward_raw(z, p_dev, mean, alpha, self.D, self.num_stages,
@@ -261,7 +272,7 @@ class NormFlow(DensityEstimator):
                     z, log_det = bijector(z, p_dev[:, idx:idx + n])
                     idx += n
                 log_q = log_q - log_det
-        for bijector in self.bijectors[self._n_core:]:  # parameter-free support layer (:385-386)
+        for bijector in ([] if support_done else self.bijectors[self._n_core:]):  # parameter-free support layer (:385-386)
             z, log_det = bijector(z)
             log_q = log_q - log_det
         if home != dev:
@@ -316,6 +327,10 @@ class NormFlow(DensityEstimator):
         if not self.conditioner:
             params = self.params
         if self._n_core < len(self.bijectors):
+            sup = self._fused_support()
+            if sup is not False and self._ar_fused_ok(z, params):
+                # ToInterval^-1 in the load stage of the one-kernel AR path
+                return ops.ar_flow_log_prob_raw(z, params, *self._ar_args(), interval_consts=sup)[0]
             # support layer first (it is the last bijector of the stack), then the core's density:
             # log q(z) = log q_core(s^-1(z)) - log|det ds| -- same sum as density_estimator.py:395-416
             zc, ld_support = self.bijectors[-1].inverse_and_log_det(z)

@@ -713,14 +713,17 @@ def _ar_common(z, params, masks, bn_mean, bn_alpha, D):
     return dev, zc, pc, pstride, mk, mean, alpha, Mz, Mp, M, N, _workspace(nbytes, dev), nbytes
 
 
-def ar_flow_log_prob_raw(z, params, masks, bn_mean, bn_alpha, D, L, U, want_lp=True, want_z0=False, want_sld=False):
-    """tnf_ar_flow_log_prob_f32 -> (log_prob | None, z0 | None, sum_log_det | None) on z's device."""
+def ar_flow_log_prob_raw(z, params, masks, bn_mean, bn_alpha, D, L, U, want_lp=True, want_z0=False, want_sld=False,
+                         interval_consts=None):
+    """tnf_ar_flow_log_prob_f32 -> (log_prob | None, z0 | None, sum_log_det | None) on z's device.
+    interval_consts: the (7, D) device constants of a ToInterval support layer fused into the kernel."""
     home = z.device
     dev, zc, pc, pstride, mk, mean, alpha, Mz, Mp, M, N, ws, nbytes = _ar_common(z, params, masks, bn_mean, bn_alpha, D)
     lp = torch.empty((M, N), dtype=torch.float32, device=dev) if want_lp else None
     z0 = torch.empty((M, N, D), dtype=torch.float32, device=dev) if want_z0 else None
     sld = torch.empty((M, N), dtype=torch.float32, device=dev) if want_sld else None
     check(lib.tnf_ar_flow_log_prob_f32(zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), mean.data_ptr(), alpha.data_ptr(),
+                                       None if interval_consts is None else interval_consts.data_ptr(),
                                        lp.data_ptr() if want_lp else None, z0.data_ptr() if want_z0 else None,
                                        sld.data_ptr() if want_sld else None, Mz, Mp, N, D, L, U, pstride,
                                        ws.data_ptr(), nbytes, _lib.stream_ptr()))
@@ -729,13 +732,14 @@ def ar_flow_log_prob_raw(z, params, masks, bn_mean, bn_alpha, D, L, U, want_lp=T
     return lp, z0, sld
 
 
-def ar_flow_forward_raw(omega, params, masks, bn_mean, bn_alpha, D, L, U):
+def ar_flow_forward_raw(omega, params, masks, bn_mean, bn_alpha, D, L, U, interval_consts=None):
     """tnf_ar_flow_forward_f32 (cached BatchNorm statistics) -> (z, sum_log_det) on the compute device."""
     dev, zc, pc, pstride, mk, mean, alpha, Mz, Mp, M, N, ws, nbytes = _ar_common(omega, params, masks, bn_mean,
                                                                                bn_alpha, D)
     z = torch.empty((M, N, D), dtype=torch.float32, device=dev)
     sld = torch.empty((M, N), dtype=torch.float32, device=dev)
     check(lib.tnf_ar_flow_forward_f32(zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), mean.data_ptr(), alpha.data_ptr(),
+                                      None if interval_consts is None else interval_consts.data_ptr(),
                                       z.data_ptr(), sld.data_ptr(), Mz, Mp, N, D, L, U, pstride, ws.data_ptr(), nbytes,
                                       _lib.stream_ptr()))
     return z, sld
