@@ -295,10 +295,13 @@ int tnf_flow_fused_supported(int32_t D, int32_t num_stages, int32_t num_layers, 
 
 /* NormFlow.log_prob (density_estimator.py:408-416) = inverse_and_log_det
  * (density_estimator.py:390-406) + base Gaussian.  Outputs, each optional (NULL):
- *   log_prob (M,N), z0 (M,N,D) the base-space point, sum_log_det (M,N). */
+ *   log_prob (M,N), z0 (M,N,D) the base-space point, sum_log_det (M,N).
+ * interval_consts (here and in tnf_flow_forward_f32): NULL, or the (7, D) constants of a ToInterval
+ * support layer appended to the stack (see tnf_to_interval), evaluated in the whole-flow kernel's
+ * load stage (log_prob) / store stage (forward); only with the whole-flow kernel (else TNF_EUNSUPPORTED). */
 int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_mean,
-                          const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det,
-                          int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_stages,
+                          const float* bn_alpha, const float* interval_consts, float* log_prob, float* z0,
+                          float* sum_log_det, int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_stages,
                           int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                           int32_t fusion, void* workspace, int64_t workspace_bytes, void* stream);
 
@@ -327,8 +330,8 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
  * the stack.  Outputs: z_out (M,N,D); sum_log_det (M,N) = sum of the forward
  * log-dets (the caller subtracts it from the base log-density, :387). */
 int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
-                         const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z,
-                         int64_t M_p, int64_t N, int32_t D, int32_t num_stages, int32_t num_layers,
+                         const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
+                         int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_stages, int32_t num_layers,
                          int32_t num_units, int64_t params_row_stride, int32_t fusion,
                          void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -56,10 +56,10 @@ def test_argument_checks_return_codes_without_launching():
     assert rc == -1 and b"dtype" in lib.tnf_last_error()
     rc = lib.tnf_coupling(_lib.F32, dummy, dummy, None, dummy, 1, 1, 4, 8, 2, 15, 1, 0, 1000, 0, None)
     assert rc == -1 and b"NULL" in lib.tnf_last_error()
-    rc = lib.tnf_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, 1, 1, 4, 6, 1, 2, 15, 10000,
+    rc = lib.tnf_flow_log_prob_f32(dummy, dummy, dummy, dummy, None, dummy, None, None, 1, 1, 4, 6, 1, 2, 15, 10000,
                                    0, dummy, 1 << 30, None)
     assert rc == _lib.EUNSUPPORTED and b"no fused kernel" in lib.tnf_last_error()
-    rc = lib.tnf_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, None, None, 1, 1, 4, 64, 4, 2, 15, 20464,
+    rc = lib.tnf_flow_log_prob_f32(dummy, dummy, dummy, dummy, None, dummy, None, None, 1, 1, 4, 64, 4, 2, 15, 20464,
                                    0, dummy, 16, None)
     assert rc == -4 and b"workspace" in lib.tnf_last_error()
     assert lib.tnf_set_option(99, 1) == -1

@@ -164,3 +164,31 @@ def test_fused_support_ar(tnf):
         torch.testing.assert_close(lp, lp2.detach(), rtol=1e-4, atol=20 * tol)
         # forward / log_prob consistency through the support layer
         assert float((lq.float() - lp).abs().max()) < 5e-2
+
+
+def test_fused_support_coupling(tnf):
+    """NormFlow('coupling', support_layer=ToInterval) with the whole-flow kernel: ToInterval runs in the kernel's
+    load (log_prob) / store (frozen forward) stage; compared with the standalone-kernel composition."""
+    for D, S, M, N in [(64, 4, 1, 3000), (32, 2, 2, 257)]:
+        np.random.seed(D)
+        torch.manual_seed(D)
+        lb = np.where(np.arange(D) % 3 == 0, -np.inf, -3.0 - np.arange(D) / 16.0)
+        ub = np.where(np.arange(D) % 3 == 1, np.inf, 3.5 + np.arange(D) / 8.0)
+        nf = tnf.NormFlow(D, True, "coupling", S, 2, 15, tnf.ToInterval(D, lb, ub))
+        g = torch.Generator().manual_seed(D)
+        for b in nf._bn_layers():
+            b.set_last_stats(torch.randn(D, generator=g) * 0.05, torch.rand(D, generator=g) * 0.2 + 0.9)
+        params = (torch.randn(M, nf.D_params, generator=g) * 0.05).cuda()
+        omega = torch.randn(M, N, D, generator=g).clamp_(-2.5, 2.5).cuda()
+        with torch.no_grad():
+            assert nf._whole_flow() and nf._fused_support() is not None
+            z, lq = nf._forward_from(omega, params, freeze_bn=True)
+            lp = nf.log_prob(z, params)
+            nf.fusion = tnf._lib.FUSE_LAYER  # per-layer chain: the support layer runs as its own kernel
+            z2, lq2 = nf._forward_from(omega, params, freeze_bn=True)
+            lp2 = nf.log_prob(z2, params)
+            nf.fusion = tnf._lib.FUSE_AUTO
+        torch.testing.assert_close(z, z2, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(lq, lq2, rtol=1e-5, atol=2e-3)
+        torch.testing.assert_close(lp, lp2, rtol=1e-5, atol=5e-3)
+        assert float((lq.float() - lp).abs().max()) < 5e-2

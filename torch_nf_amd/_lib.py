@@ -70,14 +70,14 @@ SIGNATURES = {
     "tnf_base_log_density_f64": (ctypes.c_int, [_i32, _vp, _vp, _i64, _i32, _vp]),
     "tnf_flow_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32, _i32, _i32, _i32]),
     "tnf_flow_fused_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
-    "tnf_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
+    "tnf_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
                                              _i32, _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
     "tnf_flow_train_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "tnf_flow_log_prob_fwd_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32,
                                                  _i32, _i64, _vp, _i64, _vp]),
     "tnf_flow_log_prob_bwd_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
                                                  _i32, _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
-    "tnf_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+    "tnf_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                             _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
 }
 

@@ -558,7 +558,8 @@ static int flow_common_checks(const char* fn, int64_t M_z, int64_t M_p, int64_t 
 }
 
 int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_mean,
-                          const float* bn_alpha, float* log_prob, float* z0, float* sum_log_det,
+                          const float* bn_alpha, const float* interval_consts, float* log_prob, float* z0,
+                          float* sum_log_det,
                           int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L,
                           int32_t U, int64_t pstride, int32_t fusion, void* workspace,
                           int64_t workspace_bytes, void* stream) {
@@ -582,9 +583,11 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
     const bool narrow = mfma_supported(D, L, U);
     const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
     const bool f16 = use_fused && g_flow_variant >= 10;  // builds its own (split-f16) images
+    if (interval_consts && !f16)
+        return fail(TNF_EUNSUPPORTED, "tnf_flow_log_prob_f32: a fused support layer needs the whole-flow kernel");
     if (f16)  // ONE launch: the flow kernel builds its split-f16 operands and folds BN / Affine in its prologue
         return launch_flow_fused_f16(z, nullptr, nullptr, nullptr, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U,
-                                     1, g_flow_variant, st, params, pstride, bn_mean, bn_alpha);
+                                     1, g_flow_variant, st, params, pstride, bn_mean, bn_alpha, interval_consts);
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride, 1, st);
     if (rc) return rc;
     if (!narrow) {
@@ -773,7 +776,8 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
 }
 
 int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
-                         const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M_z,
+                         const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
+                         int64_t M_z,
                          int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,
                          int64_t pstride, int32_t fusion, void* workspace, int64_t workspace_bytes,
                          void* stream) {
@@ -797,9 +801,11 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
     const bool narrow = mfma_supported(D, L, U);
     const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
     const bool f16 = use_fused && g_flow_variant >= 10;
+    if (interval_consts && !f16)
+        return fail(TNF_EUNSUPPORTED, "tnf_flow_forward_f32: a fused support layer needs the whole-flow kernel");
     if (f16)
         return launch_flow_fused_f16(omega, nullptr, nullptr, nullptr, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L,
-                                     U, 0, g_flow_variant, st, params, pstride, bn_mean, bn_alpha);
+                                     U, 0, g_flow_variant, st, params, pstride, bn_mean, bn_alpha, interval_consts);
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride, 0, st);
     if (rc) return rc;
     if (!narrow) {

@@ -222,7 +222,7 @@ static size_t flow_lds_bytes_rt(int D, int S, int L) {
 bool flow_fused_supported(int D, int S, int L, int U) {
     if (!mfma_supported(D, L, U)) return false;
     if (S < 1) return false;
-    return flow_lds_bytes_rt(D, S, L) <= 160 * 1024;
+    return flow_lds_bytes_rt(D, S, L) <= 160 * 1024 - 2048;  // room for the fused support layer's constants
 }
 
 template <int H, int L, bool INV, int NT, int NW>

@@ -20,6 +20,7 @@
 //   hidden / output:   v_mfma_f32_16x16x16_f16 (K = 16: lane (s,q) supplies units 4q..4q+3,
 //                      which is exactly where the previous accumulator left them)
 #include "mfma_tile.h"
+#include "support_math.h"
 #include "tnf_common.h"
 
 namespace tnf {
@@ -307,6 +308,7 @@ struct FlowF16Args {
     int64_t pstride, stage_stride, affine_off;  // floats per stage; offset of the Affine block inside a stage
     int64_t low_off;                            // offset of RealNVP(lower) inside a stage
     int U;
+    const float* iv;  // (7, D) constants of a fused ToInterval support layer, or NULL
 };
 
 template <int H, int NT>
@@ -344,6 +346,7 @@ flow_fused_f16_kernel(FlowF16Args a) {
     float* fold = lds + nl * Img::FLOATS;
     int* qhead = reinterpret_cast<int*>(fold + nl * 2 * D);
     float* red = fold + nl * 2 * D + 4;  // [NWAVES] partial log-det constants
+    float* ivc = red + NWAVES;           // [7][D] ToInterval constants (only read when a.iv)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -399,7 +402,10 @@ flow_fused_f16_kernel(FlowF16Args a) {
             if (lane == 0) red[wave] = acc;
         }
         if (threadIdx.x == 0) *qhead = NWAVES;
+        if (a.iv)
+            for (int i = threadIdx.x; i < 7 * D; i += NWAVES * 64) ivc[i] = a.iv[i];
     }
+    const bool has_iv = a.iv != nullptr;
     __syncthreads();
 
     const float* zb = a.z + mz * a.N * D;
@@ -439,15 +445,32 @@ flow_fused_f16_kernel(FlowF16Args a) {
         const int64_t nxt = g_lo + __builtin_amdgcn_readfirstlane(nxt_off);
         const bool has_next = nxt < g_hi;
         f4 lo[NT][HT], hi[NT][HT];
-        float ssum[NT];
+        float ssum[NT], ssup[NT];  // ssup: log-det of the fused support layer (natural log, this lane's features)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             ssum[t] = 0.f;
+            ssup[t] = 0.f;
 #pragma unroll
             for (int mm = 0; mm < HT; ++mm) {
                 lo[t][mm] = nlo[t][mm];
                 hi[t][mm] = nhi[t][mm];
             }
+        }
+        if (INV && has_iv) {  // the support layer is the first bijector of the inverse pass
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float o, l;
+                        interval_fast<true>(lo[t][mm][j], ivc, D, 16 * mm + 4 * q + j, o, l);
+                        lo[t][mm][j] = o;
+                        ssup[t] += l;
+                        interval_fast<true>(hi[t][mm][j], ivc, D, H + 16 * mm + 4 * q + j, o, l);
+                        hi[t][mm][j] = o;
+                        ssup[t] += l;
+                    }
         }
         if (has_next) {
 #pragma unroll
@@ -486,11 +509,27 @@ flow_fused_f16_kernel(FlowF16Args a) {
         } else {
             for (int st = 0; st < a.S; ++st) stage_fwd(st);
         }
+        if (!INV && has_iv) {  // ... and the last one of the forward pass
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float o, l;
+                        interval_fast<false>(lo[t][mm][j], ivc, D, 16 * mm + 4 * q + j, o, l);
+                        lo[t][mm][j] = o;
+                        ssup[t] += l;
+                        interval_fast<false>(hi[t][mm][j], ivc, D, H + 16 * mm + 4 * q + j, o, l);
+                        hi[t][mm][j] = o;
+                        ssup[t] += l;
+                    }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int64_t row = (grp * NT + t) * 16 + s;
             const bool row_ok = row < a.N;
-            const float ld_tot = __builtin_fmaf(reduce_q(ssum[t]), kLn2, ldc);
+            const float ld_tot = __builtin_fmaf(reduce_q(ssum[t]), kLn2, ldc) + (has_iv ? reduce_q(ssup[t]) : 0.f);
             if (INV && lpo) {
                 float sq = 0.f;
 #pragma unroll
@@ -542,7 +581,8 @@ int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D
 
 template <int H, int L, bool INV, int NT, int NW, int SS = 0>
 static int launch16_t(const FlowF16Args& a, int64_t M, hipStream_t st) {
-    const size_t smem = (size_t)2 * a.S * (F16Image<H, L>::FLOATS + 2 * 2 * H) * sizeof(float) + 16 + NW * sizeof(float);
+    const size_t smem = (size_t)2 * a.S * (F16Image<H, L>::FLOATS + 2 * 2 * H) * sizeof(float) + 16 + NW * sizeof(float) +
+                        7 * 2 * H * sizeof(float);
     auto kern = flow_fused_f16_kernel<H, L, INV, NT, NW, SS>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_fused_f16: cannot reserve %zu B of LDS", smem);
@@ -579,14 +619,15 @@ static int launch16_h(const FlowF16Args& a, int L, int inverse, int64_t M, int v
 int launch_flow_fused_f16(const float* z, const float* images, const float* fold, const float* ldc,
                           float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
                           int64_t N, int D, int S, int L, int U, int inverse, int variant, hipStream_t st,
-                          const float* params, int64_t pstride, const float* bn_mean, const float* bn_alpha) {
+                          const float* params, int64_t pstride, const float* bn_mean, const float* bn_alpha,
+                          const float* interval_consts) {
     const int64_t M = Mz > Mp ? Mz : Mp;
     if (N <= 0) return TNF_OK;
     if ((!fold || !images) && (!params || !bn_mean || !bn_alpha))
         return fail(TNF_EINVAL, "flow_fused_f16: nothing to build the operands from");
     const FlowLayout fl = flow_layout(D, S, L, U);
     FlowF16Args a{z, images, fold, ldc, z_out, sum_log_det, log_prob, Mz, Mp, N, mfma_image_floats(D, 3), S,
-                  params, bn_mean, bn_alpha, pstride, fl.stage, fl.p_up + fl.p_low, fl.p_up, U};
+                  params, bn_mean, bn_alpha, pstride, fl.stage, fl.p_up + fl.p_low, fl.p_up, U, interval_consts};
     int rc = (D == 64) ? launch16_h<32>(a, L, inverse, M, variant, st) : launch16_h<16>(a, L, inverse, M, variant, st);
     if (rc != TNF_OK) return rc;
     return check_launch("flow_fused_f16");

@@ -127,7 +127,8 @@ int launch_flow_fused_f16(const float* z, const float* images, const float* fold
                           float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
                           int64_t N, int D, int S, int L, int U, int inverse, int variant, hipStream_t st,
                           const float* params = nullptr, int64_t pstride = 0, const float* bn_mean = nullptr,
-                          const float* bn_alpha = nullptr);  // fold == NULL: folded inside the kernel from these
+                          const float* bn_alpha = nullptr,  // fold == NULL: folded inside the kernel from these
+                          const float* interval_consts = nullptr);  // fused ToInterval support layer (7, D)
 
 int launch_affine(int dtype, const void* z, const void* params, void* z_out, void* log_det,
                   int64_t Mz, int64_t Mp, int64_t N, int D, int inverse, int64_t pstride,

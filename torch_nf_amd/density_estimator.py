@@ -186,6 +186,10 @@ class NormFlow(DensityEstimator):
         return (maf._masks_for(torch.float32), bn.get_last_mean().detach(), bn.get_last_alpha().detach(), self.D,
                 self.num_layers, self.num_units)
 
+    def _whole_flow(self):
+        """Does the fused coupling path run as ONE kernel (the only one with a fused support stage)?"""
+        return ops.resolve_fusion(self.D, self.num_stages, self.num_layers, self.num_units, self.fusion) == _lib.FUSE_FLOW
+
     def _fused_support(self):
         """The (7, D) device constants of a ToInterval support layer that the one-kernel paths evaluate in
         their load / store stage, or None (no support layer).  Other support layers are not fused."""
@@ -259,9 +263,12 @@ class NormFlow(DensityEstimator):
             support_done = True
         elif freeze_bn and self._fused_ok(z, p_dev):
             mean, alpha = self._bn_stats(dev)
+            fuse_sup = (sup is not None and sup is not False and self._whole_flow())
             z, sld = ops.flow_forward_raw(z, p_dev, mean, alpha, self.D, self.num_stages,
-                                          self.num_layers, self.num_units, self.fusion)
+                                          self.num_layers, self.num_units, self.fusion,
+                                          interval_consts=sup if fuse_sup else None)
             log_q = log_q - sld
+            support_done = fuse_sup
         else:
             idx = 0
             for bijector in self.bijectors[:self._n_core]:
@@ -331,6 +338,10 @@ class NormFlow(DensityEstimator):
             if sup is not False and self._ar_fused_ok(z, params):
                 # ToInterval^-1 in the load stage of the one-kernel AR path
                 return ops.ar_flow_log_prob_raw(z, params, *self._ar_args(), interval_consts=sup)[0]
+            if sup is not False and self._fused_ok(z, params) and self._whole_flow():
+                mean, alpha = self._bn_stats(_lib.require_device())  # ... or of the whole-flow coupling kernel
+                return ops.flow_log_prob_raw(z, params, mean, alpha, self.D, self.num_stages, self.num_layers,
+                                             self.num_units, self.fusion, interval_consts=sup)[0]
             # support layer first (it is the last bijector of the stack), then the core's density:
             # log q(z) = log q_core(s^-1(z)) - log|det ds| -- same sum as density_estimator.py:395-416
             zc, ld_support = self.bijectors[-1].inverse_and_log_det(z)

@@ -303,8 +303,9 @@ def _workspace(nbytes, dev):
 
 
 def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO,
-                      want_z0=False, want_sld=False, want_lp=True):
-    """tnf_flow_log_prob_f32.  Returns (log_prob | None, z0 | None, sum_log_det | None)."""
+                      want_z0=False, want_sld=False, want_lp=True, interval_consts=None):
+    """tnf_flow_log_prob_f32.  Returns (log_prob | None, z0 | None, sum_log_det | None).
+    interval_consts: (7, D) device constants of a ToInterval support layer fused into the whole-flow kernel."""
     _check3(z)
     dev = _lib.require_device()
     home = z.device
@@ -327,6 +328,7 @@ def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE
     ws = _workspace(ws_bytes, dev)
     check(lib.tnf_flow_log_prob_f32(
         zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+        None if interval_consts is None else interval_consts.data_ptr(),
         lp.data_ptr() if want_lp else None, z0.data_ptr() if want_z0 else None,
         sld.data_ptr() if want_sld else None, Mz, Mp, N, D, S, L, U, pstride, fusion, ws.data_ptr(),
         ws.numel(), _lib.stream_ptr()))
@@ -337,7 +339,7 @@ def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE
     return lp, z0, sld
 
 
-def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO):
+def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO, interval_consts=None):
     """tnf_flow_forward_f32 (frozen BatchNorm).  Returns (z (M,N,D), sum_log_det (M,N))."""
     _check3(omega)
     dev = _lib.require_device()
@@ -359,6 +361,7 @@ def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.F
     ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, L, U, fusion))
     ws = _workspace(ws_bytes, dev)
     check(lib.tnf_flow_forward_f32(oc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+                                   None if interval_consts is None else interval_consts.data_ptr(),
                                    z_out.data_ptr(), sld.data_ptr(), Mz, Mp, N, D, S, L, U, pstride,
                                    fusion, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
     if home != dev:
