@@ -126,6 +126,8 @@ def test_cond_flow_weight_scaling(tnf, oracle):
     (64, 4, 2, 15, 32, [64, 64], 300, 3, True),
     (32, 2, 3, 15, 5, [50], 130, 3, False),
     (64, 2, 2, 16, 5, [128], 77, 1, True),
+    (64, 4, 2, 15, 32, [64, 64], 300, 5, True),   # variant 5: walk without g_h + the separate g_h kernel
+    (32, 2, 3, 15, 5, [50], 130, 5, False),
 ])
 def test_cond_flow_training_gradients(tnf, oracle, D, S, L, U, Dx, hidden, M, variant, weighted):
     """-(w * log_prob).mean() through the fused training pair (tnf_cond_flow_log_prob_fwd/bwd_f32): gradients of

@@ -107,7 +107,11 @@ __device__ __forceinline__ float bcast16(f4 v, int k, int c) {
     return __shfl(sel, c + 16 * (k >> 2));
 }
 
-template <int DT, int KS, int BT, int NW>
+// GH: accumulate the conditioner gradient g_h in this kernel (transposed image stream + one more MFMA group
+// per tile pair).  With 32 contexts per wave that does not fit the registers of two waves per SIMD, and with
+// 16 the operand reads saturate the LDS; GH = false leaves g_h to cond_gh_kernel, which reads the deltas
+// this kernel writes.
+template <int DT, int KS, int BT, int NW, bool GH>
 __global__ void __launch_bounds__(64 * NW)
 cond_flow_bwd_kernel(CondBwdArgs a) {
     constexpr int D = 16 * DT, Hd = D / 2, HT = DT / 2, JT = 2 * KS;
@@ -119,7 +123,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
     u4* tstage = pstage + PStream::LDS_U4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    float* gzb = reinterpret_cast<float*>(tstage + TStream::LDS_U4) + wave * (CT * ZS);  // [CT][ZS] g_z
+    float* gzb = reinterpret_cast<float*>(tstage + (GH ? TStream::LDS_U4 : 0)) + wave * (CT * ZS);  // [CT][ZS] g_z
 
     const int64_t m0 = ((int64_t)blockIdx.x * NW + wave) * CT;
     const int CR = 3 * Hd + 32 * a.L, DR = 2 * Hd + 32 * a.L;
@@ -157,7 +161,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
     TilePipe<KS, BT, PStream> pipe;
     TStream tq;
     pipe.init(a.pimg, pstage, a.T, lane);
-    tq.init(a.timg, tstage, a.T / 2);
+    if constexpr (GH) tq.init(a.timg, tstage, a.T / 2);
 
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     f4 gacc[BT][JT];
@@ -168,6 +172,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
 
     // g_h += Wpair^T (H x 32 params) . B (32 params x 16 contexts), B = xsel * d8 per lane
     auto pair_gh = [&](const float (&xsel)[BT], const float (&d8)[BT][8]) {
+        if constexpr (!GH) return;
         const u4* tp = tq.next();
         h8 Bh[BT], Bl[BT];
 #pragma unroll
@@ -226,7 +231,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                     *reinterpret_cast<f4*>(drec[bt] + 16 * o + 4 * q) = vt;
                     *reinterpret_cast<f4*>(drec[bt] + Hd + 16 * o + 4 * q) = vs;
                 }
-                gather8(vt, vs, c, q, d8o[o][bt]);
+                if constexpr (GH) gather8(vt, vs, c, q, d8o[o][bt]);
             }
         // ---- output layer: U -> Hd; its inputs are the activations of hidden level L-1 ----
         f4 dht[BT], dhs[BT], Pt[BT], Ps[BT];
@@ -288,7 +293,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                     *reinterpret_cast<f4*>(drec[bt] + 2 * Hd + 32 * l + 4 * q) = dht[bt];
                     *reinterpret_cast<f4*>(drec[bt] + 2 * Hd + 32 * l + 16 + 4 * q) = dhs[bt];
                 }
-                gather8(dht[bt], dhs[bt], c, q, d8[bt]);
+                if constexpr (GH) gather8(dht[bt], dhs[bt], c, q, d8[bt]);
             }
             if (l > 0) {
                 f4 nt[BT], ns[BT];
@@ -409,7 +414,7 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
                         *reinterpret_cast<f4*>(dr + 16 * t + 4 * q) = ga;
                         *reinterpret_cast<f4*>(dr + D + 16 * t + 4 * q) = gsh;
                     }
-                    gather8(ga, gsh, c, q, d8[bt]);
+                    if constexpr (GH) gather8(ga, gsh, c, q, d8[bt]);
                 }
                 pair_gh(ones, d8);
             }
@@ -420,9 +425,11 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
 #pragma unroll
     for (int bt = 0; bt < BT; ++bt) {
         if (live[bt]) {
+            if constexpr (GH) {
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-                *reinterpret_cast<f4*>(a.g_h + mrow[bt] * a.ldgh + 16 * jt + 4 * q) = gacc[bt][jt] * (inv / gsc);
+                for (int jt = 0; jt < JT; ++jt)
+                    *reinterpret_cast<f4*>(a.g_h + mrow[bt] * a.ldgh + 16 * jt + 4 * q) = gacc[bt][jt] * (inv / gsc);
+            }
             if (a.g_z) {
 #pragma unroll
                 for (int t = 0; t < DT; ++t)
@@ -431,6 +438,172 @@ cond_flow_bwd_kernel(CondBwdArgs a) {
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------
+// g_h on its own (after cond_flow_bwd_kernel<..., GH = false>): g_h[m,:] = sum_p gP[m,p] W[p,:] with
+// gP[m,(k,o)] = x[m,k] delta[m,o] rebuilt in registers from the saved activations and the deltas, the
+// transposed operand image streamed through a 4-slot LDS ring.  No per-context state in LDS at all.
+// ---------------------------------------------------------------------------
+template <int DT, int KS, int BT, int NW>
+__global__ void __launch_bounds__(64 * NW)
+cond_gh_kernel(CondBwdArgs a) {
+    constexpr int D = 16 * DT, Hd = D / 2, HT = DT / 2, JT = 2 * KS;
+    constexpr int CT = 16 * BT;
+    typedef TileStream<KS * 256, 4 / KS, NW, 4> TStream;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u4* tstage = reinterpret_cast<u4*>(smem_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t m0 = ((int64_t)blockIdx.x * NW + wave) * CT;
+    const int CR = 3 * Hd + 32 * a.L, DR = 2 * Hd + 32 * a.L;
+    const int U = a.U;
+    const float gsc = cond_gscale(*a.gmaxbits);
+    const float inv = *a.inv_scale;
+    int64_t mrow[BT];
+    bool live[BT];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+        const int64_t m = m0 + bt * 16 + c;
+        live[bt] = m < a.M;
+        mrow[bt] = live[bt] ? m : a.M - 1;
+    }
+    TStream tq;
+    tq.init(a.timg, tstage, a.T / 2);
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 gacc[BT][JT];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) gacc[bt][jt] = zero;
+    auto pair_gh = [&](const float (&xsel)[BT], const float (&d8)[BT][8]) {
+        const u4* tp = tq.next();
+        h8 Bh[BT], Bl[BT];
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            const float x = xsel[bt];
+            csplit8((f4){x * d8[bt][0], x * d8[bt][1], x * d8[bt][2], x * d8[bt][3]},
+                    (f4){x * d8[bt][4], x * d8[bt][5], x * d8[bt][6], x * d8[bt][7]}, Bh[bt], Bl[bt]);
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const h8 ah = __builtin_bit_cast(h8, tp[(jt * 2 + 0) * 64 + lane]);
+            const h8 al = __builtin_bit_cast(h8, tp[(jt * 2 + 1) * 64 + lane]);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) gacc[bt][jt] = cmfma32h(ah, Bh[bt], gacc[bt][jt]);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) gacc[bt][jt] = cmfma32h(al, Bh[bt], gacc[bt][jt]);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) gacc[bt][jt] = cmfma32h(ah, Bl[bt], gacc[bt][jt]);
+        }
+    };
+    float ones[BT];
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) ones[bt] = 1.f;
+    // this lane's 8 deltas of a 16-vector stored at `p` (t net) / `p + sstride` (s net): elements 8(q&1)..+7 of net q>>1
+    auto load8 = [&](const float* p, int sstride, float (&out)[8]) {
+        const float* src = p + (q >> 1) * sstride + 8 * (q & 1);
+        const f4 v0 = *reinterpret_cast<const f4*>(src), v1 = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            out[j] = v0[j];
+            out[4 + j] = v1[j];
+        }
+    };
+    auto coupling_gh = [&](int slot) {
+        const float* rec[BT];
+        const float* drec[BT];
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+            rec[bt] = a.acts_c + ((int64_t)slot * a.M + mrow[bt]) * CR;
+            drec[bt] = a.d_c + ((int64_t)slot * a.M + mrow[bt]) * DR;
+        }
+        {   // output layer: inputs = hidden level L-1, deltas [t (Hd) | s (Hd)]
+            float d8o[HT][BT][8];
+            f4 hat[BT], has[BT];
+            const int aoff = 3 * Hd + 32 * (a.L - 1);
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                hat[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 4 * q);
+                has[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 16 + 4 * q);
+#pragma unroll
+                for (int o = 0; o < HT; ++o) load8(drec[bt] + 16 * o, Hd, d8o[o][bt]);
+            }
+            for (int k = 0; k < U; ++k) {
+                float xsel[BT];
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    const float xt = bcast16(hat[bt], k, c), xs = bcast16(has[bt], k, c);
+                    xsel[bt] = q < 2 ? xt : xs;
+                }
+#pragma unroll
+                for (int o = 0; o < HT; ++o) pair_gh(xsel, d8o[o]);
+            }
+#pragma unroll
+            for (int o = 0; o < HT; ++o) pair_gh(ones, d8o[o]);
+        }
+        for (int l = a.L - 1; l >= 0; --l) {  // hidden layers L-1..1, then layer 0: deltas of level l
+            float d8[BT][8];
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) load8(drec[bt] + 2 * Hd + 32 * l, 16, d8[bt]);
+            if (l > 0) {
+                f4 hat[BT], has[BT];
+                const int aoff = 3 * Hd + 32 * (l - 1);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    hat[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 4 * q);
+                    has[bt] = *reinterpret_cast<const f4*>(rec[bt] + aoff + 16 + 4 * q);
+                }
+                for (int k = 0; k < U; ++k) {
+                    float xsel[BT];
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) {
+                        const float xt = bcast16(hat[bt], k, c), xs = bcast16(has[bt], k, c);
+                        xsel[bt] = q < 2 ? xt : xs;
+                    }
+                    pair_gh(xsel, d8);
+                }
+            } else {
+                f4 x1v[BT][HT];
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+                    for (int t = 0; t < HT; ++t) x1v[bt][t] = *reinterpret_cast<const f4*>(rec[bt] + 16 * t + 4 * q);
+                for (int k = 0; k < Hd; ++k) {
+                    float x[BT];
+#pragma unroll
+                    for (int bt = 0; bt < BT; ++bt) {
+                        f4 v = x1v[bt][0];
+#pragma unroll
+                        for (int t = 1; t < HT; ++t) v = (k >> 4) == t ? x1v[bt][t] : v;
+                        x[bt] = bcast16(v, k & 15, c);
+                    }
+                    pair_gh(x, d8);
+                }
+            }
+            pair_gh(ones, d8);
+        }
+    };
+    for (int stage = 0; stage < a.S; ++stage) {
+        const int si = a.S - 1 - stage;
+        coupling_gh(2 * si + 1);
+        coupling_gh(2 * si);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            float d8[BT][8];
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) load8(a.d_aff + ((int64_t)si * a.M + mrow[bt]) * 2 * D + 16 * t, D, d8[bt]);
+            pair_gh(ones, d8);
+        }
+    }
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+        if (live[bt]) {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                *reinterpret_cast<f4*>(a.g_h + mrow[bt] * a.ldgh + 16 * jt + 4 * q) = gacc[bt][jt] * (inv / gsc);
+        }
 }
 
 // ---------------------------------------------------------------------------
@@ -720,12 +893,26 @@ int64_t cond_flow_bwd_workspace(int D, int S, int L, int U, int H) {
 }
 
 template <int DT, int KS, int BT, int NW>
+static int launch_gh(const CondBwdArgs& a, hipStream_t st) {
+    typedef TileStream<KS * 256, 4 / KS, NW, 4> TStream;
+    const size_t smem = (size_t)TStream::LDS_U4 * 16;
+    auto k = cond_gh_kernel<DT, KS, BT, NW>;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const int64_t per_wg = (int64_t)NW * 16 * BT;
+    const int64_t blocks = (a.M + per_wg - 1) / per_wg;
+    if (blocks > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "cond_gh: grid too large");
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a);
+    return check_launch("cond_gh");
+}
+
+template <int DT, int KS, int BT, int NW, bool GH>
 static int launch_bwd_variant(const CondBwdArgs& a, hipStream_t st) {
     typedef TileStream<KS * 128 + 4, kCondG<KS>, NW, 2> PStream;
     typedef TileStream<KS * 256, 4 / KS, NW, 2> TStream;
     constexpr int D = 16 * DT;
-    const size_t smem = (size_t)(PStream::LDS_U4 + TStream::LDS_U4) * 16 + (size_t)NW * 16 * BT * (D + 4) * 4;
-    auto k = cond_flow_bwd_kernel<DT, KS, BT, NW>;
+    const size_t smem = (size_t)(PStream::LDS_U4 + (GH ? TStream::LDS_U4 : 0)) * 16 + (size_t)NW * 16 * BT * (D + 4) * 4;
+    auto k = cond_flow_bwd_kernel<DT, KS, BT, NW, GH>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int64_t per_wg = (int64_t)NW * 16 * BT;
@@ -738,14 +925,18 @@ static int launch_bwd_variant(const CondBwdArgs& a, hipStream_t st) {
 template <int DT, int KS>
 static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) {
     int v = g_cond_variant;
-    // (BT 1, 8 waves) beats (BT 2, 8 waves) here: the latter spills (the g_h accumulators, two operand
-    // slots and the gathered deltas do not fit 256 VGPRs at two waves per SIMD)
-    if (v == 0) v = a.M >= 256 * 128 ? 2 : 1;
+    // many contexts: the walk without g_h at 32 contexts per wave + the separate g_h kernel (10.4 + 9.4 ms at
+    // 2^20 contexts) beats the single kernel, which at 32 contexts per wave spills (g_h accumulators, two
+    // operand slots and the gathered deltas exceed 256 VGPRs) and at 16 saturates the LDS (22 ms)
+    if (v == 0) v = a.M >= 256 * 128 ? 5 : 1;
     int rc;
-    if (v == 4) rc = launch_bwd_variant<DT, KS, 2, 4>(a, st);
-    else if (v == 3) rc = launch_bwd_variant<DT, KS, 2, 8>(a, st);
-    else if (v == 2) rc = launch_bwd_variant<DT, KS, 1, 8>(a, st);
-    else rc = launch_bwd_variant<DT, KS, 1, 4>(a, st);
+    if (v == 5) {  // the walk without g_h at 32 contexts per wave, then g_h on its own
+        rc = launch_bwd_variant<DT, KS, 2, 8, false>(a, st);
+        if (!rc) rc = launch_gh<DT, KS, 2, 8>(a, st);
+    } else if (v == 4) rc = launch_bwd_variant<DT, KS, 2, 4, true>(a, st);
+    else if (v == 3) rc = launch_bwd_variant<DT, KS, 2, 8, true>(a, st);
+    else if (v == 2) rc = launch_bwd_variant<DT, KS, 1, 8, true>(a, st);
+    else rc = launch_bwd_variant<DT, KS, 1, 4, true>(a, st);
     if (rc) return rc;
     const CondCfg& c = g.cfg;
     const int jobs = c.S * (2 * 2 * (c.L + c.HT) + 2 * c.DT);
