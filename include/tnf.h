@@ -210,11 +210,11 @@ int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, c
  * saves, in `acts` (tnf_cond_flow_acts_floats(M, D, S, L) floats), the activations the backward needs.
  * tnf_cond_flow_log_prob_bwd_f32: from g_log_prob (M) to the gradients of param_net's last Linear --
  * g_W (D_params, ldgw), g_b (D_params), both overwritten -- and of its input, g_h (M, ldgh); g_z (M, D)
- * optional (NULL).  `deltas` is scratch of tnf_cond_flow_deltas_floats(M, D, S, L) floats; the workspace
+ * optional (NULL).  `deltas` is scratch of tnf_cond_flow_deltas_floats(M, D, S, L, H) floats; the workspace
  * needs tnf_cond_flow_bwd_workspace_bytes.  Neither params (M, D_params) nor their gradient is ever
  * materialised (torch autograd through the reference would hold both: 2 x 82 KB per context at D = 64). */
 int64_t tnf_cond_flow_acts_floats(int64_t M, int32_t D, int32_t num_stages, int32_t num_layers);
-int64_t tnf_cond_flow_deltas_floats(int64_t M, int32_t D, int32_t num_stages, int32_t num_layers);
+int64_t tnf_cond_flow_deltas_floats(int64_t M, int32_t D, int32_t num_stages, int32_t num_layers, int32_t H);
 int64_t tnf_cond_flow_bwd_workspace_bytes(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units,
                                           int32_t H);
 int tnf_cond_flow_log_prob_fwd_f32(const float* z, const float* h, const float* W, const float* b,

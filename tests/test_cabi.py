@@ -108,7 +108,7 @@ def test_widened_entries_host_side(oracle):
     assert lib.tnf_cond_flow_workspace_bytes(64, 4, 2, 15, 50) == _lib.EUNSUPPORTED
     M = 1000
     assert lib.tnf_cond_flow_acts_floats(M, 64, 4, 2) == 4 * M * 64 + 8 * M * (3 * 32 + 64)
-    assert lib.tnf_cond_flow_deltas_floats(M, 64, 4, 2) == 8 * M * 64 + 8 * M * (64 + 64)
+    assert lib.tnf_cond_flow_deltas_floats(M, 64, 4, 2, 64) == 8 * M * 64 + 8 * M * (64 + 64) + 1024 * 64
     rc = lib.tnf_cond_flow_log_prob_f32(dummy, dummy, dummy, dummy, dummy, dummy, dummy, None, None, 10, 64, 4, 2, 15,
                                         64, 62, 64, dummy, ws, None)
     assert rc == -1 and b"multiples of 4" in lib.tnf_last_error()

@@ -399,9 +399,10 @@ int64_t tnf_cond_flow_acts_floats(int64_t M, int32_t D, int32_t S, int32_t L) {
     return cond_acts_floats(M, D, S, L);
 }
 
-int64_t tnf_cond_flow_deltas_floats(int64_t M, int32_t D, int32_t S, int32_t L) {
-    if (M < 0 || D < 2 || S < 1 || L < 1) return fail(TNF_EINVAL, "tnf_cond_flow_deltas_floats: M=%lld D=%d S=%d L=%d", (long long)M, D, S, L);
-    return cond_deltas_floats(M, D, S, L);
+int64_t tnf_cond_flow_deltas_floats(int64_t M, int32_t D, int32_t S, int32_t L, int32_t H) {
+    if (M < 0 || D < 2 || S < 1 || L < 1 || H < 1)
+        return fail(TNF_EINVAL, "tnf_cond_flow_deltas_floats: M=%lld D=%d S=%d L=%d H=%d", (long long)M, D, S, L, H);
+    return cond_deltas_floats(M, D, S, L, H);
 }
 
 int64_t tnf_cond_flow_bwd_workspace_bytes(int32_t D, int32_t S, int32_t L, int32_t U, int32_t H) {

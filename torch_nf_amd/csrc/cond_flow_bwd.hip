@@ -625,6 +625,7 @@ struct GwArgs {
     float* g_W;   // (D_params, ldgw), zero-initialised
     float* g_b;   // (D_params), zero-initialised
     const unsigned* gmaxbits;
+    const u4* himg;  // h as split-f16 MFMA B operands: [32-context group][jt][hi/lo][lane] (cond_hsplit_kernel)
     int64_t M, ldh, ldgw;
     CondCfg cfg;
     int jobs, spp;  // jobs per context slice; 128-context (64 at H = 128) steps per slice
@@ -702,21 +703,48 @@ __device__ inline GwJob gw_job(const GwArgs& a, int job) {
     return j;
 }
 
+// h (M, ldh) -> ready B operands of the g_W contraction, split once for all jobs: group g = contexts
+// 32g..32g+31; lane (j = lane & 15, q = lane >> 4) of tile jt holds contexts 32g + 8q .. +7 of hidden unit
+// 16 jt + j (zero past M).  One wave per (group, jt).
+template <int KS>
+__global__ void __launch_bounds__(256)
+cond_hsplit_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, u4* __restrict__ himg) {
+    constexpr int JT = 2 * KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int64_t ngroups = (M + 31) / 32;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + wave; w < ngroups * JT; w += (int64_t)gridDim.x * 4) {
+        const int64_t g = w / JT;
+        const int jt = (int)(w - g * JT);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t m = 32 * g + 8 * q + e;
+            const float x = h[(m < M ? m : M - 1) * ldh + 16 * jt + j];
+            v[e] = m < M ? x : 0.f;
+        }
+        h8 hi, lo;
+        csplit8((f4){v[0], v[1], v[2], v[3]}, (f4){v[4], v[5], v[6], v[7]}, hi, lo);
+        himg[((g * JT + jt) * 2 + 0) * 64 + lane] = __builtin_bit_cast(u4, hi);
+        himg[((g * JT + jt) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u4, lo);
+    }
+}
+
 template <int DT, int KS, int NW>
 __global__ void __launch_bounds__(64 * NW)
 cond_gw_kernel(GwArgs a) {
-    constexpr int Hd = 8 * DT, JT = 2 * KS, H = 32 * KS, NT = 64 * NW;
+    constexpr int Hd = 8 * DT, JT = 2 * KS, NT = 64 * NW;
     constexpr int IPW = (Hd + 1 + NW - 1) / NW;  // items (input units + the bias) per wave
     constexpr int CH = KS == 4 ? 64 : 128;        // contexts staged per step
     constexpr int CS = CH + 4;                    // padded row stride of the transposed staging buffers
     constexpr int XQ = Hd / 4;                    // float4 per context row, at most
     constexpr int NX = (CH * XQ + NT - 1) / NT, ND = (CH * 4 + NT - 1) / NT;
-    constexpr int NHP = (CH / 8 * H + NT - 1) / NT;  // (hidden unit, context octet) pairs per thread
+    constexpr int HB_U4 = (CH / 32) * JT * 2 * 64;  // one step's h operands (32 KB at H = 64)
     __shared__ __attribute__((aligned(16))) float xT[(Hd + 1) * CS];
     __shared__ __attribute__((aligned(16))) float dT[16 * CS];
-    // h as ready MFMA B operands, split once per step for all waves: [sub-step][jt][hi/lo][lane], lane
-    // (j = lane & 15, q = lane >> 4) = contexts 8q..8q+7 of hidden unit 16 jt + j
-    __shared__ __attribute__((aligned(16))) u4 hB[(CH / 32) * JT * 2 * 64];
+    // h as ready MFMA B operands [sub-step][jt][hi/lo][lane], copied from the pre-split image by LDS-DMA
+    // (contiguous), two slots
+    __shared__ __attribute__((aligned(16))) u4 hB[2 * HB_U4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own
@@ -740,7 +768,15 @@ cond_gw_kernel(GwArgs a) {
 
     // register-staged prefetch of one step: x rows, delta rows, h rows of CH contexts (zero past M)
     f4 px[NX], pd[ND];
-    float ph[NHP][8];
+    const int64_t himg_u4 = ((a.M + 31) / 32) * JT * 2 * 64;
+    auto fetch_h = [&](int64_t step, int slot) {  // asynchronous: lands in hB[slot] before the barrier after next
+        const int64_t base = step * HB_U4;
+        for (int i = wave; i < HB_U4 / 64; i += NW) {
+            int64_t g = base + i * 64 + lane;
+            g = g < himg_u4 ? g : himg_u4 - 1;  // past the last group: never used (x and delta are zero there)
+            __builtin_amdgcn_global_load_lds(a.himg + g, (lds_void*)(hB + slot * HB_U4 + i * 64), 16, 0, 0);
+        }
+    };
     auto fetch = [&](int64_t mbase) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -759,18 +795,6 @@ cond_gw_kernel(GwArgs a) {
             const bool ok = ctx < CH && m < a.M;
             const f4 v = *reinterpret_cast<const f4*>(job.d + (ok ? m : 0) * job.dstr + 4 * o4);
             pd[i] = ok ? v : zero;
-        }
-#pragma unroll
-        for (int i = 0; i < NHP; ++i) {
-            const int idx = tid + i * NT;
-            const int oct = idx / H, j = idx - oct * H;  // consecutive threads -> consecutive hidden units
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int64_t m = mbase + 8 * oct + e;
-                const bool ok = oct < CH / 8 && m < a.M;
-                const float v = a.h[(ok ? m : 0) * a.ldh + j];
-                ph[i][e] = ok ? v : 0.f;
-            }
         }
     };
     auto commit = [&]() {
@@ -793,46 +817,33 @@ cond_gw_kernel(GwArgs a) {
                 for (int e = 0; e < 4; ++e) dT[(4 * o4 + e) * CS + ctx] = (4 * o4 + e < job.count) ? pd[i][e] : 0.f;
             }
         }
-#pragma unroll
-        for (int i = 0; i < NHP; ++i) {
-            const int idx = tid + i * NT;
-            const int oct = idx / H, j = idx - oct * H;
-            if (oct < CH / 8) {
-                h8 hi, lo;
-                csplit8((f4){ph[i][0], ph[i][1], ph[i][2], ph[i][3]}, (f4){ph[i][4], ph[i][5], ph[i][6], ph[i][7]}, hi, lo);
-                const int slot = (((oct >> 2) * JT + (j >> 4)) * 2) * 64 + (j & 15) + 16 * (oct & 3);
-                hB[slot] = __builtin_bit_cast(u4, hi);
-                hB[slot + 64] = __builtin_bit_cast(u4, lo);
-            }
-        }
     };
 
     const int64_t nsteps = (a.M + CH - 1) / CH;
     int64_t st = (int64_t)split * a.spp;
     const int64_t st_end = (st + a.spp) < nsteps ? (st + a.spp) : nsteps;
     const int64_t st_first = st;
-    (void)st_first;  // only the TNF_COND_ABLATE == 3 experiment reads it
-    if (st < st_end) fetch(st * CH);
+    if (st < st_end) {
+        fetch(st * CH);
+        fetch_h(st, 0);
+    }
     for (; st < st_end; ++st) {
-#if TNF_COND_ABLATE == 3  // timing experiment: stage only the first step
-        if (st == st_first) {
-            commit();
-            __syncthreads();
-        }
-#else
-        __syncthreads();  // everyone is done reading the previous step
+        const int cur = (int)((st - st_first) & 1);
+        __syncthreads();  // everyone is done with the previous step; its vmcnt(0) also retires h of this step
         commit();
-        __syncthreads();
+        if (st + 1 < st_end) fetch_h(st + 1, cur ^ 1);  // the other slot was last read two barriers ago
+        // raw barrier: a __syncthreads() here would wait (vmcnt(0)) for the copy just requested
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (st + 1 < st_end) fetch((st + 1) * CH);  // in flight during the MFMAs below
-#endif
+        const u4* hcur = hB + cur * HB_U4;
 #pragma unroll
         for (int sub = 0; sub < CH / 32; ++sub) {
             const int co = 32 * sub + 8 * q;
             h8 Bh[JT], Bl[JT];
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
-                Bh[jt] = __builtin_bit_cast(h8, hB[((sub * JT + jt) * 2 + 0) * 64 + lane]);
-                Bl[jt] = __builtin_bit_cast(h8, hB[((sub * JT + jt) * 2 + 1) * 64 + lane]);
+                Bh[jt] = __builtin_bit_cast(h8, hcur[((sub * JT + jt) * 2 + 0) * 64 + lane]);
+                Bl[jt] = __builtin_bit_cast(h8, hcur[((sub * JT + jt) * 2 + 1) * 64 + lane]);
             }
             const f4 d0 = *reinterpret_cast<const f4*>(dT + r * CS + co);
             const f4 d1 = *reinterpret_cast<const f4*>(dT + r * CS + co + 4);
@@ -884,7 +895,10 @@ cond_gw_kernel(GwArgs a) {
 // Host side
 // ---------------------------------------------------------------------------
 int64_t cond_acts_floats(int64_t M, int D, int S, int L) { return (int64_t)S * M * D + 2 * (int64_t)S * M * (3 * (D / 2) + 32 * L); }
-int64_t cond_deltas_floats(int64_t M, int D, int S, int L) { return 2 * (int64_t)S * M * D + 2 * (int64_t)S * M * (D + 32 * L); }
+// deltas of every layer + the pre-split h image of the g_W kernel (H floats per context, 32-context groups)
+int64_t cond_deltas_floats(int64_t M, int D, int S, int L, int H) {
+    return 2 * (int64_t)S * M * D + 2 * (int64_t)S * M * (D + 32 * L) + ((M + 31) / 32) * 32 * (int64_t)H;
+}
 
 int64_t cond_flow_bwd_workspace(int D, int S, int L, int U, int H) {
     const CondCfg c = cond_cfg(D, S, L, U, H);
@@ -949,6 +963,13 @@ static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) 
     GwArgs gg = g;
     gg.jobs = jobs;
     gg.spp = (int)spp;
+    {
+        const int64_t waves = ((a.M + 31) / 32) * 2 * KS;
+        int64_t hb = (waves + 3) / 4;
+        if (hb > 4096) hb = 4096;
+        hipLaunchKernelGGL((cond_hsplit_kernel<KS>), dim3((unsigned)hb), dim3(256), 0, st, g.h, g.ldh, a.M,
+                           const_cast<u4*>(g.himg));
+    }
     if (split * jobs > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "cond_gw: grid too large");
     hipLaunchKernelGGL((cond_gw_kernel<DT, KS, 8>), dim3((unsigned)(split * jobs)), dim3(512), 0, st, gg);
     return check_launch("cond_gw");
@@ -987,6 +1008,7 @@ int launch_cond_flow_backward(const float* g_lp, const float* h, const float* W,
     GwArgs g;
     g.h = h; g.acts_c = a.acts_c; g.d_c = a.d_c; g.d_aff = a.d_aff; g.g_W = g_W; g.g_b = g_b;
     g.M = M; g.ldh = ldh; g.ldgw = ldgw; g.cfg = cfg; g.gmaxbits = gmax;
+    g.himg = reinterpret_cast<const u4*>(a.d_c + 2 * (int64_t)S * M * (D + 32 * L));  // 16-byte aligned: all terms are
     if (D == 64) {
         if (KS == 1) return launch_bwd_dk<4, 1>(a, g, st);
         if (KS == 2) return launch_bwd_dk<4, 2>(a, g, st);

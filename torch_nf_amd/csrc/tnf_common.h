@@ -182,7 +182,7 @@ int launch_cond_flow_log_prob(const float* z, const float* h, const float* W, co
                               int64_t M, int D, int S, int L, int U, int H, int64_t ldh, int64_t ldw, void* ws,
                               hipStream_t st);
 int64_t cond_acts_floats(int64_t M, int D, int S, int L);
-int64_t cond_deltas_floats(int64_t M, int D, int S, int L);
+int64_t cond_deltas_floats(int64_t M, int D, int S, int L, int H);
 int64_t cond_flow_bwd_workspace(int D, int S, int L, int U, int H);
 int launch_cond_flow_backward(const float* g_lp, const float* h, const float* W, const float* b, const float* bn_mean,
                               const float* bn_alpha, const float* acts, float* deltas, float* g_h, float* g_W,

@@ -674,7 +674,7 @@ class _CondFlowLogProbFn(torch.autograd.Function):
         g_w = torch.empty((P, Hp), dtype=torch.float32, device=dev)
         g_b = torch.empty((P,), dtype=torch.float32, device=dev)
         g_z = torch.zeros((M, D), dtype=torch.float32, device=dev) if need_z else None
-        deltas = torch.empty((max(1, check(lib.tnf_cond_flow_deltas_floats(M, D, S, L))),), dtype=torch.float32,
+        deltas = torch.empty((max(1, check(lib.tnf_cond_flow_deltas_floats(M, D, S, L, Hp))),), dtype=torch.float32,
                              device=dev)
         nbytes = check(lib.tnf_cond_flow_bwd_workspace_bytes(D, S, L, U, Hp))
         ws = _workspace(nbytes, dev)
