@@ -631,36 +631,50 @@ struct GwArgs {
     int jobs, spp;  // jobs per context slice; 128-context (64 at H = 128) steps per slice
 };
 
-struct GwJob {
+// A job = up to four SEGMENTS that share the staged h operands: a segment is one (MLP layer, net, 16-output
+// tile) -- d_in weight rows + one bias row, one delta tile -- or one Affine 16-feature tile (bias row only).
+// The t and s nets of the hidden / output layers are merged into one job (2 x 17 items), the four alpha or
+// shift tiles of an Affine too; the 33-item layer-0 nets stay separate.  All segments of a job have the
+// same d_in.
+struct GwSeg {
     const float* x;   // x[m * xs + k], k < d_in   (NULL: no weight items)
     const float* d;   // d[m * dstr + o], o < count
-    int64_t xs, dstr;
     int64_t wbase;    // parameter index of weight (k = 0, o = 0): + k * wk + o
     int64_t bbase;    // parameter index of bias o = 0
-    int d_in, wk, count;
+    int wk, count;
 };
+struct GwJob {
+    GwSeg seg[4];
+    int64_t xs, dstr;
+    int nseg, d_in;
+};
+
+__device__ inline int gw_jobs_per_stage(const CondCfg& c) { return 2 * (2 + (c.L - 1) + c.HT) + 2; }
 
 __device__ inline GwJob gw_job(const GwArgs& a, int job) {
     const CondCfg& c = a.cfg;
     const int Hd = c.D / 2, U = c.U, L = c.L;
-    const int JC = 2 * (L + c.HT), JA = 2 * c.DT, JS = 2 * JC + JA;
+    const int JC = 2 + (L - 1) + c.HT, JS = 2 * JC + 2;
     const int CR = 3 * Hd + 32 * L, DR = 2 * Hd + 32 * L;
     const int si = job / JS, stage = c.S - 1 - si;
     int r = job % JS;
     GwJob j;
     const int64_t so = (int64_t)stage * c.fl.stage;
-    if (r >= 2 * JC) {  // Affine tile: gP = g_alpha / g_shift themselves
-        r -= 2 * JC;
-        const int which = r & 1, t = r >> 1;
-        j.x = nullptr;
-        j.xs = 0;
+    if (r >= 2 * JC) {  // Affine: gP = g_alpha (job 0) / g_shift (job 1) themselves, one segment per 16 features
+        const int which = r - 2 * JC;
+        j.nseg = c.DT;
         j.d_in = 0;
-        j.wk = 0;
-        j.wbase = 0;
-        j.d = a.d_aff + (int64_t)si * a.M * 2 * c.D + which * c.D + 16 * t;
+        j.xs = 0;
         j.dstr = 2 * c.D;
-        j.bbase = so + c.fl.p_up + c.fl.p_low + which * c.D + 16 * t;
-        j.count = 16;
+        for (int t = 0; t < c.DT; ++t) {
+            GwSeg& g = j.seg[t];
+            g.x = nullptr;
+            g.d = a.d_aff + (int64_t)si * a.M * 2 * c.D + which * c.D + 16 * t;
+            g.wbase = 0;
+            g.wk = 0;
+            g.bbase = so + c.fl.p_up + c.fl.p_low + which * c.D + 16 * t;
+            g.count = 16;
+        }
         return j;
     }
     const int low = r < JC;  // slot 2si = RealNVP(lower), 2si+1 = RealNVP(upper)
@@ -669,36 +683,47 @@ __device__ inline GwJob gw_job(const GwArgs& a, int job) {
     const int64_t off = so + (low ? c.fl.p_up : 0);
     const float* rec = a.acts_c + (int64_t)slot * a.M * CR;
     const float* drec = a.d_c + (int64_t)slot * a.M * DR;
-    const int net = r & 1, lvl = r >> 1;
     j.xs = CR;
     j.dstr = DR;
-    if (lvl == 0) {
-        j.x = rec;
+    if (r < 2) {  // layer 0, net r
+        const int net = r;
+        j.nseg = 1;
         j.d_in = Hd;
-        j.wk = U;
-        j.count = U;
-        j.d = drec + 2 * Hd + net * 16;
-        j.wbase = off + (int64_t)net * Hd * U;
-        j.bbase = off + 2 * (int64_t)Hd * U + net * U;
-    } else if (lvl < L) {
+        GwSeg& g = j.seg[0];
+        g.x = rec;
+        g.d = drec + 2 * Hd + net * 16;
+        g.wbase = off + (int64_t)net * Hd * U;
+        g.wk = U;
+        g.bbase = off + 2 * (int64_t)Hd * U + net * U;
+        g.count = U;
+    } else if (r < 2 + (L - 1)) {  // hidden layer lvl, both nets
+        const int lvl = r - 1;
         const int64_t ol = off + 2 * (int64_t)Hd * U + 2 * U + (int64_t)(lvl - 1) * (2 * U * U + 2 * U);
-        j.x = rec + 3 * Hd + 32 * (lvl - 1) + net * 16;
+        j.nseg = 2;
         j.d_in = U;
-        j.wk = U;
-        j.count = U;
-        j.d = drec + 2 * Hd + 32 * lvl + net * 16;
-        j.wbase = ol + (int64_t)net * U * U;
-        j.bbase = ol + 2 * (int64_t)U * U + net * U;
-    } else {
-        const int ot = lvl - L;
+        for (int net = 0; net < 2; ++net) {
+            GwSeg& g = j.seg[net];
+            g.x = rec + 3 * Hd + 32 * (lvl - 1) + net * 16;
+            g.d = drec + 2 * Hd + 32 * lvl + net * 16;
+            g.wbase = ol + (int64_t)net * U * U;
+            g.wk = U;
+            g.bbase = ol + 2 * (int64_t)U * U + net * U;
+            g.count = U;
+        }
+    } else {  // output layer, tile ot, both nets
+        const int ot = r - 2 - (L - 1);
         const int64_t oo = off + 2 * (int64_t)Hd * U + 2 * U + (int64_t)(L - 1) * (2 * U * U + 2 * U);
-        j.x = rec + 3 * Hd + 32 * (L - 1) + net * 16;
+        j.nseg = 2;
         j.d_in = U;
-        j.wk = Hd;
-        j.count = 16;
-        j.d = drec + net * Hd + 16 * ot;
-        j.wbase = oo + (int64_t)net * U * Hd + 16 * ot;
-        j.bbase = oo + 2 * (int64_t)U * Hd + net * Hd + 16 * ot;
+        for (int net = 0; net < 2; ++net) {
+            GwSeg& g = j.seg[net];
+            g.x = rec + 3 * Hd + 32 * (L - 1) + net * 16;
+            g.d = drec + net * Hd + 16 * ot;
+            g.wbase = oo + (int64_t)net * U * Hd + 16 * ot;
+            g.wk = Hd;
+            g.bbase = oo + 2 * (int64_t)U * Hd + net * Hd + 16 * ot;
+            g.count = 16;
+        }
     }
     return j;
 }
@@ -733,28 +758,31 @@ cond_hsplit_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, u4* __re
 template <int DT, int KS, int NW>
 __global__ void __launch_bounds__(64 * NW)
 cond_gw_kernel(GwArgs a) {
-    constexpr int Hd = 8 * DT, JT = 2 * KS, NT = 64 * NW;
-    constexpr int IPW = (Hd + 1 + NW - 1) / NW;  // items (input units + the bias) per wave
+    constexpr int JT = 2 * KS, NT = 64 * NW;
+    constexpr int XR = 32;                        // staged x rows: one 32-wide layer-0 input or 2 x 16 hidden units
+    constexpr int IPW = (XR + 2 + NW - 1) / NW;   // items (weight rows + bias rows of all segments) per wave
     constexpr int CH = KS == 4 ? 64 : 128;        // contexts staged per step
     constexpr int CS = CH + 4;                    // padded row stride of the transposed staging buffers
-    constexpr int XQ = Hd / 4;                    // float4 per context row, at most
-    constexpr int NX = (CH * XQ + NT - 1) / NT, ND = (CH * 4 + NT - 1) / NT;
+    constexpr int NX = (CH * (XR / 4) + NT - 1) / NT, ND = (CH * 16 + NT - 1) / NT;
     constexpr int HB_U4 = (CH / 32) * JT * 2 * 64;  // one step's h operands (32 KB at H = 64)
-    __shared__ __attribute__((aligned(16))) float xT[(Hd + 1) * CS];
-    __shared__ __attribute__((aligned(16))) float dT[16 * CS];
+    __shared__ __attribute__((aligned(16))) float xT[(XR + 1) * CS];   // row XR: ones (the bias items)
+    __shared__ __attribute__((aligned(16))) float dT[4 * 16 * CS];     // one delta tile per segment
     // h as ready MFMA B operands [sub-step][jt][hi/lo][lane], copied from the pre-split image by LDS-DMA
     // (contiguous), two slots
     __shared__ __attribute__((aligned(16))) u4 hB[2 * HB_U4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own
-    // L2.  All jobs of one context slice are given ids of the same residue mod 8, so the slice's h rows
-    // (a.spp steps, ~1 MB) are fetched into ONE L2 and re-read there by the other jobs.
+    // L2.  All jobs of one context slice are given ids of the same residue mod 8, so the slice's h image
+    // (a.spp steps, ~1 MB) is fetched into ONE L2 and re-read there by the other jobs.
     const int xcd = blockIdx.x & 7, tq = blockIdx.x >> 3;
     const int split = xcd + 8 * (tq / a.jobs);
-    const GwJob job = gw_job(a, tq % a.jobs);
-    const int items = job.d_in + 1;
-    const int xq = (job.d_in + 3) >> 2;  // float4 per context row of x actually read (rows are padded to 4)
+    __shared__ GwJob job;  // in LDS: its segments are indexed dynamically
+    if (tid == 0) job = gw_job(a, tq % a.jobs);
+    __syncthreads();
+    const int ips = job.d_in + 1;                 // items per segment
+    const int items = job.nseg * ips;
+    const int xq = (job.d_in + 3) >> 2;           // float4 per segment row of x actually read (rows are padded to 4)
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     f4 acc[IPW][JT];
     float gb[IPW];
@@ -764,9 +792,9 @@ cond_gw_kernel(GwArgs a) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) acc[i][jt] = zero;
     }
-    for (int i = tid; i < CS; i += NT) xT[job.d_in * CS + i] = 1.f;  // the bias item multiplies by one
+    for (int i = tid; i < CS; i += NT) xT[XR * CS + i] = 1.f;
 
-    // register-staged prefetch of one step: x rows, delta rows, h rows of CH contexts (zero past M)
+    // register-staged prefetch of one step: x rows and delta rows of CH contexts (zero past M)
     f4 px[NX], pd[ND];
     const int64_t himg_u4 = ((a.M + 31) / 32) * JT * 2 * 64;
     auto fetch_h = [&](int64_t step, int slot) {  // asynchronous: lands in hB[slot] before the barrier after next
@@ -777,23 +805,26 @@ cond_gw_kernel(GwArgs a) {
             __builtin_amdgcn_global_load_lds(a.himg + g, (lds_void*)(hB + slot * HB_U4 + i * 64), 16, 0, 0);
         }
     };
+    const int xrow4 = job.nseg * xq;  // float4 per context over all segments
     auto fetch = [&](int64_t mbase) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = tid + i * NT;
-            const int ctx = xq ? idx / xq : 0, k4 = xq ? idx - ctx * xq : 0;
+            const int ctx = xrow4 ? idx / xrow4 : 0, k4g = xrow4 ? idx - ctx * xrow4 : 0;
+            const int sg = xq ? k4g / xq : 0, k4 = xq ? k4g - sg * xq : 0;
             const int64_t m = mbase + ctx;
-            const bool ok = xq && ctx < CH && m < a.M;
-            const f4 v = *reinterpret_cast<const f4*>((ok ? job.x + m * job.xs + 4 * k4 : a.h));
+            const bool ok = xrow4 && ctx < CH && m < a.M;
+            const f4 v = *reinterpret_cast<const f4*>((ok ? job.seg[sg].x + m * job.xs + 4 * k4 : a.h));
             px[i] = ok ? v : zero;
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int idx = tid + i * NT;
-            const int ctx = idx >> 2, o4 = idx & 3;
+            const int ctx = idx / (4 * job.nseg), rem = idx - ctx * 4 * job.nseg;
+            const int sg = rem >> 2, o4 = rem & 3;
             const int64_t m = mbase + ctx;
             const bool ok = ctx < CH && m < a.M;
-            const f4 v = *reinterpret_cast<const f4*>(job.d + (ok ? m : 0) * job.dstr + 4 * o4);
+            const f4 v = *reinterpret_cast<const f4*>(job.seg[sg].d + (ok ? m : 0) * job.dstr + 4 * o4);
             pd[i] = ok ? v : zero;
         }
     };
@@ -801,23 +832,35 @@ cond_gw_kernel(GwArgs a) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = tid + i * NT;
-            const int ctx = xq ? idx / xq : 0, k4 = xq ? idx - ctx * xq : 0;
-            if (xq && ctx < CH) {
+            const int ctx = xrow4 ? idx / xrow4 : 0, k4g = xrow4 ? idx - ctx * xrow4 : 0;
+            const int sg = xq ? k4g / xq : 0, k4 = xq ? k4g - sg * xq : 0;
+            if (xrow4 && ctx < CH) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (4 * k4 + e < job.d_in) xT[(4 * k4 + e) * CS + ctx] = px[i][e];
+                    if (4 * k4 + e < job.d_in) xT[(sg * job.d_in + 4 * k4 + e) * CS + ctx] = px[i][e];
             }
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int idx = tid + i * NT;
-            const int ctx = idx >> 2, o4 = idx & 3;
+            const int ctx = idx / (4 * job.nseg), rem = idx - ctx * 4 * job.nseg;
+            const int sg = rem >> 2, o4 = rem & 3;
             if (ctx < CH) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dT[(4 * o4 + e) * CS + ctx] = (4 * o4 + e < job.count) ? pd[i][e] : 0.f;
+                for (int e = 0; e < 4; ++e)
+                    dT[(sg * 16 + 4 * o4 + e) * CS + ctx] = (4 * o4 + e < job.seg[sg].count) ? pd[i][e] : 0.f;
             }
         }
     };
+    // item -> (segment, x row in xT)
+    int iseg[IPW], irow[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int it = wave + i * NW;
+        const int sg = it / ips, k = it - sg * ips;
+        iseg[i] = sg < job.nseg ? sg : 0;
+        irow[i] = k < job.d_in ? sg * job.d_in + k : XR;
+    }
 
     const int64_t nsteps = (a.M + CH - 1) / CH;
     int64_t st = (int64_t)split * a.spp;
@@ -845,14 +888,13 @@ cond_gw_kernel(GwArgs a) {
                 Bh[jt] = __builtin_bit_cast(h8, hcur[((sub * JT + jt) * 2 + 0) * 64 + lane]);
                 Bl[jt] = __builtin_bit_cast(h8, hcur[((sub * JT + jt) * 2 + 1) * 64 + lane]);
             }
-            const f4 d0 = *reinterpret_cast<const f4*>(dT + r * CS + co);
-            const f4 d1 = *reinterpret_cast<const f4*>(dT + r * CS + co + 4);
 #pragma unroll
             for (int i = 0; i < IPW; ++i) {
-                const int k = wave + i * NW;
-                if (k < items) {  // wave-uniform
-                    const f4 a0 = *reinterpret_cast<const f4*>(xT + k * CS + co) * d0;
-                    const f4 a1 = *reinterpret_cast<const f4*>(xT + k * CS + co + 4) * d1;
+                if (wave + i * NW < items) {  // wave-uniform
+                    const float* dr = dT + (iseg[i] * 16 + r) * CS + co;
+                    const float* xr = xT + irow[i] * CS + co;
+                    const f4 a0 = *reinterpret_cast<const f4*>(xr) * *reinterpret_cast<const f4*>(dr);
+                    const f4 a1 = *reinterpret_cast<const f4*>(xr + 4) * *reinterpret_cast<const f4*>(dr + 4);
                     gb[i] += (a0[0] + a0[1]) + (a0[2] + a0[3]) + (a1[0] + a1[1]) + (a1[2] + a1[3]);
                     h8 ah, al;
 #if TNF_COND_ABLATE == 4  // timing experiment: no operand split
@@ -874,19 +916,21 @@ cond_gw_kernel(GwArgs a) {
     // ---- merge: rows of the accumulators = outputs 4q + jj, columns = hidden unit 16 jt + r ----
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-        const int k = wave + i * NW;
-        if (k < items) {
-            const int64_t pb = k < job.d_in ? job.wbase + (int64_t)k * job.wk : job.bbase;
+        const int it = wave + i * NW;
+        if (it < items) {
+            const int sg = it / ips, k = it - sg * ips;
+            const GwSeg& g = job.seg[sg];
+            const int64_t pb = k < job.d_in ? g.wbase + (int64_t)k * g.wk : g.bbase;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int o = 4 * q + jj;
-                if (o < job.count) {
+                if (o < g.count) {
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt) atomicAdd(a.g_W + (pb + o) * a.ldgw + 16 * jt + r, acc[i][jt][jj] * ig);
                 }
             }
-            const float s = reduce_q(gb[i]);
-            if (q == 0 && r < job.count) atomicAdd(a.g_b + pb + r, s * ig);
+            const float sres = reduce_q(gb[i]);
+            if (q == 0 && r < g.count) atomicAdd(a.g_b + pb + r, sres * ig);
         }
     }
 }
@@ -953,7 +997,7 @@ static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) 
     else rc = launch_bwd_variant<DT, KS, 1, 4, true>(a, st);
     if (rc) return rc;
     const CondCfg& c = g.cfg;
-    const int jobs = c.S * (2 * 2 * (c.L + c.HT) + 2 * c.DT);
+    const int jobs = c.S * (2 * (2 + (c.L - 1) + c.HT) + 2);  // gw_job(): layer-0 nets apart, the rest merged
     const int64_t nsteps = (a.M + (KS == 4 ? 63 : 127)) / (KS == 4 ? 64 : 128);
     // context slices of ~1 MB of h rows (32 steps), at least 8 (one per XCD) when there is enough work
     int64_t spp = 32;
