@@ -325,6 +325,27 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
                               int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                               int64_t g_params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Reversible training pair for the same loss (density_estimator.py:390-416 under autograd).  The
+ * coupling stack is invertible, so the forward is the whole-flow kernel of tnf_flow_log_prob_f32
+ * and keeps only its output z0 (M,N,D); the backward is ONE kernel that walks the layers from z0,
+ * rebuilding each layer's input from its output while it back-propagates (split-f16 MFMA, fp32
+ * accumulate).  g_z may be NULL when the gradient w.r.t. z is not wanted; g_params as above
+ * (accumulated, zero it first).  BatchNorm statistics are constants.  Available when
+ * tnf_flow_train_rev_supported() is 1 (D in {32, 64}, num_units <= 16, the layers' gradient
+ * accumulators fit the 160 KB LDS). */
+int tnf_flow_train_rev_supported(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units);
+int64_t tnf_flow_train_rev_workspace_bytes(int64_t M_p, int32_t D, int32_t num_stages, int32_t num_layers,
+                                           int32_t num_units);
+int tnf_flow_log_prob_fwd_rev_f32(const float* z, const float* params, const float* bn_mean, const float* bn_alpha,
+                                  float* log_prob, float* z0, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                                  int32_t num_stages, int32_t num_layers, int32_t num_units,
+                                  int64_t params_row_stride, void* stream);
+int tnf_flow_log_prob_bwd_rev_f32(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
+                                  const float* g_log_prob, float* g_z, float* g_params, int64_t M, int64_t M_p,
+                                  int64_t N, int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units,
+                                  int64_t params_row_stride, int64_t g_params_row_stride, void* workspace,
+                                  int64_t workspace_bytes, void* stream);
+
 /* The deterministic part of NormFlow.forward with freeze_bn=True
  * (density_estimator.py:374-388): pushes base samples `omega` (M,N,D) through
  * the stack.  Outputs: z_out (M,N,D); sum_log_det (M,N) = sum of the forward

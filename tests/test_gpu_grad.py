@@ -165,11 +165,14 @@ def test_forward_path_training_grad(tnf, oracle):
     torch.testing.assert_close(nf.params.grad.cpu(), p_ref.grad, rtol=5e-3, atol=2e-5)
 
 
+@pytest.mark.parametrize("reversible", [True, False])
 @pytest.mark.parametrize("D,S,L,M,Mp,N", [(64, 4, 2, 1, 1, 300), (32, 2, 3, 3, 3, 40), (64, 2, 1, 3, 1, 33), (32, 1, 2, 2, 2, 1000)])
-def test_flow_level_training_pair(tnf, oracle, D, S, L, M, Mp, N):
-    """tnf_flow_log_prob_fwd_f32 / _bwd_f32 (what NormFlow.log_prob uses under autograd for the MFMA
-    shapes): loss and gradients w.r.t. z and the flat parameter rows vs torch autograd over the oracle,
-    including per-context parameter rows (M_p = M) and one row shared by several sample batches."""
+def test_flow_level_training_pair(tnf, oracle, D, S, L, M, Mp, N, reversible):
+    """What NormFlow.log_prob uses under autograd for the MFMA shapes -- the reversible pair
+    (tnf_flow_log_prob_fwd_rev_f32 / _bwd_rev_f32: whole-flow forward, one-kernel backward from z0) and the
+    per-layer pair (tnf_flow_log_prob_fwd_f32 / _bwd_f32): loss and gradients w.r.t. z and the flat
+    parameter rows vs torch autograd over the oracle, including per-context parameter rows (M_p = M) and
+    one row shared by several sample batches."""
     U = 15
     rng = np.random.RandomState(D + S + M)
     nf = tnf.NormFlow(D, True, "coupling", S, L, U)
@@ -186,8 +189,35 @@ def test_flow_level_training_pair(tnf, oracle, D, S, L, M, Mp, N):
     loss_ref.backward()
     p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
     assert tnf.ops.flow_train_supported(M, Mp, N, D, S, L, U)
+    assert tnf.ops.flow_train_rev_supported(M, Mp, N, D, S, L, U)
+    nf.reversible_training = reversible
+    assert nf._train_path(z, p) == ("reversible" if reversible else "layers")
     loss = (nf.log_prob(z, p) * w.cuda()).sum() / N
     loss.backward()
     torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(z.grad.cpu(), z_ref.grad, rtol=2e-4, atol=2e-6)
     torch.testing.assert_close(p.grad.cpu(), p_ref.grad, rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("D,U,N,scale", [(64, 15, 4099, 1e-7), (64, 16, 777, 1.0), (32, 15, 2500, 3e4)])
+def test_flow_reversible_backward_scales_and_no_gz(tnf, oracle, D, U, N, scale):
+    """The one-kernel backward with z a constant (g_z not requested), N not a multiple of the tile, U = 16
+    (no padded unit) and upstream gradients far from 1 (the kernel rescales g_log_prob by a power of two so
+    the split-f16 operands keep their low halves): parameter gradients vs torch autograd over the oracle."""
+    S, L = 4, 2
+    rng = np.random.RandomState(N)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.1, (1, nf.D_params))).float()
+    mean = rng.normal(0, 0.3, (2 * S, D)).astype(np.float32)
+    alpha = np.exp(rng.normal(0, 0.2, (2 * S, D))).astype(np.float32)
+    for b, m_, a_ in zip(nf._bn_layers(), mean, alpha):
+        b.set_last_stats(T(m_), T(a_))
+    stats = [(torch.from_numpy(m_), torch.from_numpy(a_)) for m_, a_ in zip(mean, alpha)]
+    z0 = torch.tensor(rng.normal(0, 1, (1, N, D))).float()
+    p_ref = p0.clone().requires_grad_()
+    (-oracle.flow_log_prob(z0, p_ref, D, S, L, U, stats).mean() * scale).backward()
+    p = p0.cuda().requires_grad_()
+    z = z0.cuda()
+    assert nf._train_path(z, p) == "reversible"
+    (-nf.log_prob(z, p).mean() * scale).backward()
+    torch.testing.assert_close(p.grad.cpu() / scale, p_ref.grad / scale, rtol=5e-4, atol=5e-5)

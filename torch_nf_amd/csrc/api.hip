@@ -776,6 +776,63 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
                                      st);
 }
 
+// ---- reversible training pair: whole-flow forward that keeps only z0, one-kernel backward ----
+int tnf_flow_train_rev_supported(int32_t D, int32_t S, int32_t L, int32_t U) {
+    return (flow_fused_supported(D, S, L, U) && flow_train_rev_supported(D, S, L, U)) ? 1 : 0;
+}
+
+int64_t tnf_flow_train_rev_workspace_bytes(int64_t M_p, int32_t D, int32_t S, int32_t L, int32_t U) {
+    if (M_p < 1) return fail(TNF_EINVAL, "tnf_flow_train_rev_workspace_bytes: M_p=%lld", (long long)M_p);
+    if (!tnf_flow_train_rev_supported(D, S, L, U))
+        return fail(TNF_EUNSUPPORTED, "tnf_flow_train_rev_workspace_bytes: D=%d S=%d L=%d U=%d", D, S, L, U);
+    return flow_train_rev_workspace(M_p, D, S, L);
+}
+
+static int rev_checks(const char* fn, int64_t M, int64_t M_p, int64_t N, int D, int S, int L, int U, int64_t pstride) {
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0)
+        return fail(TNF_EINVAL, "%s: M=%lld M_p=%lld N=%lld", fn, (long long)M, (long long)M_p, (long long)N);
+    if (!tnf_flow_train_rev_supported(D, S, L, U))
+        return fail(TNF_EUNSUPPORTED, "%s: no reversible training kernels for D=%d S=%d L=%d U=%d", fn, D, S, L, U);
+    if (pstride < flow_layout(D, S, L, U).total)
+        return fail(TNF_EINVAL, "%s: params row has %lld elements, flow needs %lld", fn, (long long)pstride,
+                    (long long)flow_layout(D, S, L, U).total);
+    return TNF_OK;
+}
+
+int tnf_flow_log_prob_fwd_rev_f32(const float* z, const float* params, const float* bn_mean, const float* bn_alpha,
+                                  float* log_prob, float* z0, int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t S,
+                                  int32_t L, int32_t U, int64_t pstride, void* stream) {
+    int rc = rev_checks("tnf_flow_log_prob_fwd_rev_f32", M, M_p, N, D, S, L, U, pstride);
+    if (rc) return rc;
+    if (N == 0) return TNF_OK;
+    if (!z || !params || !bn_mean || !bn_alpha || !log_prob || !z0)
+        return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_rev_f32: NULL pointer");
+    if (!aligned16(z) || !aligned16(z0)) return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_rev_f32: z / z0 must be 16-byte aligned");
+    return launch_flow_fused_f16(z, nullptr, nullptr, nullptr, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, 1,
+                                 g_flow_variant >= 10 ? g_flow_variant : 10, as_stream(stream), params, pstride, bn_mean,
+                                 bn_alpha, nullptr);
+}
+
+int tnf_flow_log_prob_bwd_rev_f32(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
+                                  const float* g_log_prob, float* g_z, float* g_params, int64_t M, int64_t M_p,
+                                  int64_t N, int32_t D, int32_t S, int32_t L, int32_t U, int64_t pstride,
+                                  int64_t gpstride, void* workspace, int64_t workspace_bytes, void* stream) {
+    int rc = rev_checks("tnf_flow_log_prob_bwd_rev_f32", M, M_p, N, D, S, L, U, pstride);
+    if (rc) return rc;
+    if (N == 0) return TNF_OK;
+    if (!z0 || !params || !bn_mean || !bn_alpha || !g_log_prob || !g_params)
+        return fail(TNF_EINVAL, "tnf_flow_log_prob_bwd_rev_f32: NULL pointer");
+    if (!aligned16(z0) || (g_z && !aligned16(g_z)))
+        return fail(TNF_EINVAL, "tnf_flow_log_prob_bwd_rev_f32: z0 / g_z must be 16-byte aligned");
+    if (gpstride < flow_layout(D, S, L, U).total)
+        return fail(TNF_EINVAL, "tnf_flow_log_prob_bwd_rev_f32: g_params row too short");
+    if (!workspace || workspace_bytes < flow_train_rev_workspace(M_p, D, S, L))
+        return fail(TNF_EWORKSPACE, "tnf_flow_log_prob_bwd_rev_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)flow_train_rev_workspace(M_p, D, S, L));
+    return launch_flow_bwd_rev(z0, params, bn_mean, bn_alpha, g_log_prob, g_z, g_params, M, M_p, N, D, S, L, U, pstride,
+                               gpstride, workspace, as_stream(stream));
+}
+
 int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
                          const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
                          int64_t M_z,

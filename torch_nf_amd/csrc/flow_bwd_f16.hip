@@ -1,0 +1,715 @@
+// Whole-flow backward of loss = f(NormFlow.log_prob(z)) in ONE kernel, split-f16 matrix path.
+//
+// The coupling stack is invertible, so nothing is saved by the forward except its output z0: the
+// kernel starts from (z0, g_log_prob) and walks the layers in the order opposite to the inverse
+// pass.  For each layer it
+//   1. recomputes the twin MLP on the conditioner half (unchanged by the layer) -> r, t, s;
+//   2. rebuilds the layer's input  y = y_out e^s + t  and the output deltas
+//        d y = g e^-s,  d t = -d y,  d s = -g y_out - g_log_prob;
+//   3. propagates the deltas through the MLPs with the transposed RAW weights as A operands
+//      (the accumulator -> B-operand chaining of the forward pass works unchanged);
+//   4. forms the weight gradients dW[k][o] = sum_s a[k,s] d[o,s] as MFMAs that contract over the
+//      SAMPLE index: every activation / delta tile is transposed through a wave-private LDS
+//      scratch, split, and multiplied; bias gradients are the same tiles times a ones operand;
+//   5. undoes the folded BatchNorm/Affine in front of the layer, v = (v - B)/A, g *= A, and on
+//      layers with an Affine reduces dA = sum g v, dB = sum g over the tile.
+// Every contraction is three f16 MFMAs on hi/lo-split operands with fp32 accumulate (f16_tile.h).
+// g_log_prob is pre-scaled by a power of two so that the deltas stay clear of the f16 subnormals;
+// the scale comes out again when the gradients leave the kernel.
+//
+// A wave carries one 16-sample tile through all 2S layers, so the per-layer gradient accumulators
+// cannot live in registers: they are ds_add_f32 targets in LDS (packed like the layer's parameter
+// block, 2S x ~10 KB) and leave with one global atomic per parameter per workgroup.  That leaves
+// no room for all layers' operand images, so the waves of a workgroup step through the layers
+// together: the next layer's image (forward operands | transposed operands | fold constants,
+// ~21 KB, built once per call by flow_rev_images_kernel) is prefetched into registers during a
+// step and committed to the other half of a two-slot LDS ring at its end, one barrier per step.
+#include "f16_tile.h"
+#include "tnf_common.h"
+
+namespace tnf {
+
+// Transposed raw weights as split-f16 A operands, lane (r = lane&15, q = lane>>4), 16 B per lane per group:
+//   W2 (d h_last[k] = sum_o W2[k][o] d out[o]):  m = k = r.  H = 32: K slot (q, i) is o = 16 (i>>2) + 4q + (i&3),
+//       one group of 8 hi + one of 8 lo per net;  H = 16: K = o = 4q + j, one group [hi(4) | lo(4)] per net.
+//   Wh (d h_l[k_in] = sum Wh[k_in][k_out] d a[k_out]):  m = k_in = r, K = k_out = 4q + j, [hi | lo].
+//   W0 (d x[f] = sum_u W0[f][u] d a0[u]):  m = f = 16 mm + r, K = u = 4q + j, [hi | lo] per (net, mm).
+template <int H, int L>
+struct B16Image {
+    static constexpr int HT = (H + 15) / 16;
+    static constexpr int NW2 = (H == 32) ? 4 : 2;
+    static constexpr int NWG = NW2 + 2 * (L - 1) + 2 * HT;
+    static constexpr int FLOATS = NWG * 256;
+    __device__ static constexpr int g_w2(int net, int part) { return (H == 32) ? net * 2 + part : net; }
+    __device__ static constexpr int g_wh(int l, int net) { return NW2 + 2 * l + net; }
+    __device__ static constexpr int g_w0(int net, int mm) { return NW2 + 2 * (L - 1) + net * HT + mm; }
+};
+
+// One layer's streamed image: [forward f16 image | transposed f16 image | A (D) | B (D) | 1/A (D) | -B/A (D)]
+template <int H, int L>
+struct RevImage {
+    static constexpr int D = 2 * H;
+    static constexpr int F_OFF = 0;
+    static constexpr int B_OFF = F16Image<H, L>::FLOATS;
+    static constexpr int C_OFF = B_OFF + B16Image<H, L>::FLOATS;
+    static constexpr int FLOATS = C_OFF + 4 * D;
+};
+
+template <int H, int L>
+__device__ __forceinline__ void build_b16_image(float* img, const float* __restrict__ p, int U, int lane) {
+    typedef B16Image<H, L> Img;
+    constexpr int HT = Img::HT;
+    const int r = lane & 15, q = lane >> 4;
+    u4* grp = reinterpret_cast<u4*>(img) + lane;
+    {   // layer 0: W0[f][u]
+        const float* w[2] = {p, p + H * U};
+#pragma unroll
+        for (int net = 0; net < 2; ++net)
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 16 * mm + r, u = 4 * q + j;
+                    v[j] = ld_sel(w[net], f * U + u, f < H && u < U);
+                }
+                u4 o;
+                split2(v[0], v[1], o[0], o[2]);
+                split2(v[2], v[3], o[1], o[3]);
+                grp[Img::g_w0(net, mm) * 64] = o;
+            }
+        p += 2 * H * U + 2 * U;
+    }
+#pragma unroll
+    for (int l = 0; l < L - 1; ++l) {
+        const float* w[2] = {p, p + U * U};
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ki = r, ko = 4 * q + j;
+                v[j] = ld_sel(w[net], ki * U + ko, ki < U && ko < U);
+            }
+            u4 o;
+            split2(v[0], v[1], o[0], o[2]);
+            split2(v[2], v[3], o[1], o[3]);
+            grp[Img::g_wh(l, net) * 64] = o;
+        }
+        p += 2 * U * U + 2 * U;
+    }
+    {   // output layer: W2[k][o]
+        const float* w[2] = {p, p + U * H};
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            if constexpr (H == 32) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int o = 16 * (i >> 2) + 4 * q + (i & 3);
+                    v[i] = ld_sel(w[net], r * H + o, r < U);
+                }
+                u4 hi, lo;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) split2(v[2 * pp], v[2 * pp + 1], hi[pp], lo[pp]);
+                grp[Img::g_w2(net, 0) * 64] = hi;
+                grp[Img::g_w2(net, 1) * 64] = lo;
+            } else {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ld_sel(w[net], r * H + 4 * q + j, r < U);
+                u4 o;
+                split2(v[0], v[1], o[0], o[2]);
+                split2(v[2], v[3], o[1], o[3]);
+                grp[Img::g_w2(net, 0) * 64] = o;
+            }
+        }
+    }
+}
+
+// grid (2S, Mp) x 64 threads: the streamed image of layer c of context row m
+template <int H, int L>
+__global__ void __launch_bounds__(64)
+flow_rev_images_kernel(const float* __restrict__ params, const float* __restrict__ bn_mean,
+                       const float* __restrict__ bn_alpha, float* __restrict__ rimg, int S, int U, int64_t pstride,
+                       int64_t Mp) {
+    typedef RevImage<H, L> R;
+    constexpr int D = 2 * H;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t m = grid_m();
+    if (m >= Mp) return;
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const float* prow = params + m * pstride;
+    const float* p = prow + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+    float* img = rimg + (m * 2 * S + c) * (int64_t)R::FLOATS;
+    build_f16_image<H, L>(img + R::F_OFF, p, U, lane);
+    build_b16_image<H, L>(img + R::B_OFF, p, U, lane);
+    float* fc = img + R::C_OFF;
+    for (int d = lane; d < D; d += 64) {  // the inverse-pass fold of flow_fold_kernel (coupling_mfma.hip)
+        const float alpha = bn_alpha[c * D + d], mu = bn_mean[c * D + d];
+        float ea = 1.f, shift = 0.f;
+        if (c & 1) {
+            const float* ap = prow + (c >> 1) * fl.stage + fl.p_up + fl.p_low;
+            ea = expf(ap[d]);
+            shift = ap[D + d];
+        }
+        const float A = alpha / ea, B = mu - shift * A;
+        fc[d] = A;
+        fc[D + d] = B;
+        fc[2 * D + d] = 1.f / A;
+        fc[3 * D + d] = -B / A;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+flow_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+// acc layout (lane (s, q), reg j = row 4q + j, col s)  ->  operand layout with K = samples:
+// lane (c = lane&15, kq = lane>>4) gets element [row c][samples 4 kq .. 4 kq + 3].
+constexpr int kScr = 16 * 20;  // one padded tile (rows 16-byte aligned, bank-conflict-free both ways)
+__device__ __forceinline__ f4 transpose16(f4 v, float* scr, int lane) {
+    const int s = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) scr[(4 * q + j) * 20 + s] = v[j];
+    return *reinterpret_cast<const f4*>(scr + s * 20 + 4 * q);
+}
+
+struct T16 {
+    h4 hi, lo;
+};
+__device__ __forceinline__ T16 tsplit(f4 v, float* scr, int lane) {
+    T16 o;
+    split4(transpose16(v, scr, lane), o.hi, o.lo);
+    return o;
+}
+// D[rows of a][rows of b] = sum over the 16 samples
+__device__ __forceinline__ f4 outer16h(const T16& a, const T16& b) {
+    f4 acc = mfma16h(a.hi, b.hi, f4{0.f, 0.f, 0.f, 0.f});
+    acc = mfma16h(a.lo, b.hi, acc);
+    return mfma16h(a.hi, b.lo, acc);
+}
+__device__ __forceinline__ f4 rowsum16h(const T16& a) {
+    const h4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    f4 acc = mfma16h(a.hi, ones, f4{0.f, 0.f, 0.f, 0.f});
+    return mfma16h(a.lo, ones, acc);
+}
+__device__ __forceinline__ f4 mm3(h4 wh, h4 wl, h4 xh, h4 xl, f4 acc) {
+    acc = mfma16h(wh, xh, acc);
+    acc = mfma16h(wh, xl, acc);
+    return mfma16h(wl, xh, acc);
+}
+// LDS accumulators are 32-bit FIXED POINT (value * fx): on gfx950 ds_add_f32 costs ~190 cycles per
+// wave-instruction, ds_add_u32 ~4 (scratch/lds_atomic_bench.hip), and a wave's 16-sample tile needs ~70 of them
+// per layer.  fx is chosen on the host so that 2^13 per accumulated term cannot overflow (see launch_rev);
+// amax tracks the largest term so the kernel can tell when that budget did not hold.
+struct FxAcc {
+    float fx;    // scale
+    float amax;  // largest |term| seen by this lane
+};
+__device__ __forceinline__ void lds_add1(int* p, float v, FxAcc& fa) {
+    fa.amax = fmaxf(fa.amax, fabsf(v));
+    atomicAdd(p, __float2int_rn(v * fa.fx));
+}
+__device__ __forceinline__ void lds_add4(int* p, f4 v, int ncol, FxAcc& fa) {  // columns 0..ncol-1 of this lane's 4 are real
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < ncol) lds_add1(p + j, v[j], fa);
+}
+// sum over the 16 sample lanes of a q-group (DPP row rotations), result in every lane
+__device__ __forceinline__ float rowsum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+struct FlowBwdArgs {
+    const float* z0;     // (M, N, D): output of the inverse pass
+    const float* g_lp;   // (M, N)
+    const float* rimg;   // (Mp, 2S, RevImage::FLOATS)
+    const unsigned* gmax;  // bits of max |g_lp|
+    float* g_z;          // (M, N, D) or NULL
+    float* g_params;     // (Mp, gpstride), accumulated
+    float* g_fold;       // (Mp, 2S, 2, D), accumulated (odd layers only)
+    float* glp_sum;      // (Mp), accumulated
+    int64_t M, Mp, N, gpstride, stage, low_off;
+    int S, U;
+    float fx;            // fixed-point scale of the LDS accumulators
+};
+
+// One coupling layer backwards on one tile.  x: conditioner half (= layer input and output);
+// y: in = transformed half of the OUTPUT, out = of the INPUT;  gx, gy: in = gradients wrt the layer's
+// outputs, out = wrt its inputs;  gl = d loss / d (sum of s) for this sample (natural log units).
+template <int H, int L>
+__device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& fa, float* scrA, float* scrB, int lane, int U,
+                                            const f4 (&x)[(H + 15) / 16], f4 (&y)[(H + 15) / 16],
+                                            f4 (&gx)[(H + 15) / 16], f4 (&gy)[(H + 15) / 16], float gl) {
+    typedef F16Image<H, L> FImg;
+    typedef B16Image<H, L> BImg;
+    typedef RevImage<H, L> R;
+    constexpr int HT = FImg::HT;
+    const int s = lane & 15, q = lane >> 4;
+    const u4* fg = reinterpret_cast<const u4*>(img + R::F_OFF) + lane;
+    const u4* bg = reinterpret_cast<const u4*>(img + R::B_OFF) + lane;
+    const float* bl = img + R::F_OFF + FImg::NWG * 256 + q * 4;
+    auto bias = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(bl + g * 16); };
+    auto hl = [&](const u4* base, int g, h4& hi, h4& lo) {
+        const u4 wv = base[g * 64];
+        hi = __builtin_bit_cast(h4, u2{wv[0], wv[1]});
+        lo = __builtin_bit_cast(h4, u2{wv[2], wv[3]});
+    };
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int ncol = (U - 4 * q) < 0 ? 0 : ((U - 4 * q) > 4 ? 4 : (U - 4 * q));  // real units among 4q .. 4q+3
+    const bool row_u = s < U;
+
+    // ---- 1. forward recompute ----
+    f4 r[L][2];
+    if constexpr (H == 32) {
+        u4 a_, b_;
+        split2(x[0][0], x[0][1], a_[0], b_[0]);
+        split2(x[0][2], x[0][3], a_[1], b_[1]);
+        split2(x[1][0], x[1][1], a_[2], b_[2]);
+        split2(x[1][2], x[1][3], a_[3], b_[3]);
+        const h8 xh = __builtin_bit_cast(h8, a_), xl = __builtin_bit_cast(h8, b_);
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            const h8 wh = __builtin_bit_cast(h8, fg[FImg::g_w0(net, 0) * 64]);
+            const h8 wl = __builtin_bit_cast(h8, fg[FImg::g_w0(net, 1) * 64]);
+            f4 a0 = mfma32h(wh, xh, bias(FImg::b_b0(net)));
+            a0 = mfma32h(wh, xl, a0);
+            a0 = mfma32h(wl, xh, a0);
+            r[0][net] = sig2_4(a0);
+        }
+    } else {
+        h4 xh, xl;
+        split4(x[0], xh, xl);
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            h4 wh, wl;
+            hl(fg, FImg::g_w0(net, 0), wh, wl);
+            r[0][net] = sig2_4(mm3(wh, wl, xh, xl, bias(FImg::b_b0(net))));
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < L - 1; ++l)
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            h4 rh, rl, wh, wl;
+            split4(r[l][net], rh, rl);
+            hl(fg, FImg::g_wh(l, net), wh, wl);
+            r[l + 1][net] = sig2_4(mm3(wh, wl, rh, rl, bias(FImg::b_bh(l, net))));
+        }
+    f4 dout[2][HT];
+    {
+        h4 rh[2], rl[2];
+        split4(r[L - 1][0], rh[0], rl[0]);
+        split4(r[L - 1][1], rh[1], rl[1]);
+#pragma unroll
+        for (int mo = 0; mo < HT; ++mo) {
+            h4 wh, wl;
+            hl(fg, FImg::g_w2(0, mo), wh, wl);
+            const f4 tt = mm3(wh, wl, rh[0], rl[0], bias(FImg::b_b2(0, mo)));
+            hl(fg, FImg::g_w2(1, mo), wh, wl);
+            const f4 sv = mm3(wh, wl, rh[1], rl[1], bias(FImg::b_b2(1, mo)));
+            // ---- 2. rebuild the input, output deltas ----
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = __builtin_amdgcn_exp2f(sv[j]), em = __builtin_amdgcn_exp2f(-sv[j]);
+                const float g = gy[mo][j], yo = y[mo][j];
+                const float dy = g * em;
+                dout[0][mo][j] = -dy;
+                dout[1][mo][j] = __builtin_fmaf(-g, yo, gl);
+                y[mo][j] = __builtin_fmaf(yo, e, tt[j]);
+                gy[mo][j] = dy;
+            }
+        }
+    }
+
+    // packed accumulator offsets (the layer's parameter block, bijectors.py:222-235)
+    const int o_w0 = 0, o_b0 = 2 * H * U;
+    const int o_h = o_b0 + 2 * U;                 // + l * (2 U U + 2 U)
+    const int o_w2 = o_h + (L - 1) * (2 * U * U + 2 * U), o_b2 = o_w2 + 2 * U * H;
+
+    // ---- 3. output layer: dW2, db2, d h_{L-1} ----
+    f4 dh[2];
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        f4 hcur;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hcur[j] = __builtin_fmaf(-2.f, r[L - 1][net][j], 1.f);
+        const T16 h_t = tsplit(hcur, scrB, lane);
+#pragma unroll
+        for (int mo = 0; mo < HT; ++mo) {
+            const T16 d_t = tsplit(dout[net][mo], scrA, lane);
+            const f4 dw = outer16h(d_t, h_t);  // [o = 16 mo + 4q + j][k = s]
+            if (row_u) lds_add4(acc + o_w2 + net * U * H + s * H + 16 * mo + 4 * q, dw, 4, fa);
+            const f4 db = rowsum16h(d_t);
+            if (s == 0) lds_add4(acc + o_b2 + net * H + 16 * mo + 4 * q, db, 4, fa);
+        }
+        if constexpr (H == 32) {
+            u4 a_, b_;
+            split2(dout[net][0][0], dout[net][0][1], a_[0], b_[0]);
+            split2(dout[net][0][2], dout[net][0][3], a_[1], b_[1]);
+            split2(dout[net][1][0], dout[net][1][1], a_[2], b_[2]);
+            split2(dout[net][1][2], dout[net][1][3], a_[3], b_[3]);
+            const h8 dhi = __builtin_bit_cast(h8, a_), dlo = __builtin_bit_cast(h8, b_);
+            const h8 wh = __builtin_bit_cast(h8, bg[BImg::g_w2(net, 0) * 64]);
+            const h8 wl = __builtin_bit_cast(h8, bg[BImg::g_w2(net, 1) * 64]);
+            f4 a0 = mfma32h(wh, dhi, zero);
+            a0 = mfma32h(wh, dlo, a0);
+            dh[net] = mfma32h(wl, dhi, a0);
+        } else {
+            h4 dhi, dlo, wh, wl;
+            split4(dout[net][0], dhi, dlo);
+            hl(bg, BImg::g_w2(net, 0), wh, wl);
+            dh[net] = mm3(wh, wl, dhi, dlo, zero);
+        }
+    }
+    // ---- 4. hidden layers, last to first ----
+#pragma unroll
+    for (int l = L - 2; l >= 0; --l)
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            f4 da, hprev;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float rr = r[l + 1][net][j];
+                da[j] = dh[net][j] * (4.f * rr * (1.f - rr));
+                hprev[j] = __builtin_fmaf(-2.f, r[l][net][j], 1.f);
+            }
+            const T16 d_t = tsplit(da, scrA, lane);
+            const T16 h_t = tsplit(hprev, scrB, lane);
+            const f4 dw = outer16h(d_t, h_t);  // [k_out = 4q + j][k_in = s]
+            int* ah = acc + o_h + l * (2 * U * U + 2 * U);
+            if (row_u) lds_add4(ah + net * U * U + s * U + 4 * q, dw, ncol, fa);
+            const f4 db = rowsum16h(d_t);
+            if (s == 0) lds_add4(ah + 2 * U * U + net * U + 4 * q, db, ncol, fa);
+            h4 dhi, dlo, wh, wl;
+            split4(da, dhi, dlo);
+            hl(bg, BImg::g_wh(l, net), wh, wl);
+            dh[net] = mm3(wh, wl, dhi, dlo, zero);
+        }
+    // ---- 5. first layer: dW0, db0, d x ----
+    T16 x_t[HT];
+#pragma unroll
+    for (int mm = 0; mm < HT; ++mm) x_t[mm] = tsplit(x[mm], scrB, lane);
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+        f4 da;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float rr = r[0][net][j];
+            da[j] = dh[net][j] * (4.f * rr * (1.f - rr));
+        }
+        const T16 d_t = tsplit(da, scrA, lane);
+        const f4 db = rowsum16h(d_t);
+        if (s == 0) lds_add4(acc + o_b0 + net * U + 4 * q, db, ncol, fa);
+        h4 dhi, dlo;
+        split4(da, dhi, dlo);
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            const f4 dw = outer16h(d_t, x_t[mm]);  // [u = 4q + j][f = 16 mm + s]
+            lds_add4(acc + o_w0 + net * H * U + (16 * mm + s) * U + 4 * q, dw, ncol, fa);
+            h4 wh, wl;
+            hl(bg, BImg::g_w0(net, mm), wh, wl);
+            gx[mm] = mm3(wh, wl, dhi, dlo, gx[mm]);
+        }
+    }
+}
+
+// Undo the fold in front of a layer on one half (features f0 + 16 mm + 4q + j): v <- (v - B)/A, g <- g A;
+// with AFFINE the tile's contributions to dA, dB go to the accumulators behind the layer's parameters.
+template <int H, bool AFFINE>
+__device__ __forceinline__ void unfold_half(const float* fc, int* gf, FxAcc& fa, int lane, int f0,
+                                            f4 (&v)[(H + 15) / 16], f4 (&g)[(H + 15) / 16]) {
+    constexpr int D = 2 * H;
+    constexpr int HT = (H + 15) / 16;
+    const int s = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int mm = 0; mm < HT; ++mm) {
+        const int f = f0 + 16 * mm + 4 * q;
+        const f4 A = *reinterpret_cast<const f4*>(fc + f);
+        const f4 iA = *reinterpret_cast<const f4*>(fc + 2 * D + f);
+        const f4 C = *reinterpret_cast<const f4*>(fc + 3 * D + f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float vp = __builtin_fmaf(v[mm][j], iA[j], C[j]);
+            if (AFFINE) {
+                const float da = rowsum_dpp(g[mm][j] * vp), db = rowsum_dpp(g[mm][j]);
+                if (s == 0) {
+                    lds_add1(gf + f + j, da, fa);
+                    lds_add1(gf + D + f + j, db, fa);
+                }
+            }
+            g[mm][j] *= A[j];
+            v[mm][j] = vp;
+        }
+    }
+}
+
+template <int H, int L, int NW>
+__global__ void __launch_bounds__(NW * 64)
+flow_bwd_f16_kernel(FlowBwdArgs a) {
+    typedef RevImage<H, L> R;
+    constexpr int D = 2 * H;
+    constexpr int HT = (H + 15) / 16;
+    constexpr int RU4 = R::FLOATS / 4;
+    constexpr int NPF = (RU4 + NW * 64 - 1) / (NW * 64);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nl = 2 * a.S;
+    const int U = a.U;
+    const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
+    const int ACC = (P + 2 * D + 3) & ~3;
+    float* ring = lds;                          // [2][R::FLOATS]
+    int* accb = reinterpret_cast<int*>(lds + 2 * R::FLOATS);  // [nl][ACC] fixed point
+    float* scr = lds + 2 * R::FLOATS + nl * ACC;              // [NW][2][kScr]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int64_t m = grid_m();
+    if (m >= a.M) return;
+    const int64_t mp = a.Mp == 1 ? 0 : m;
+    float* scrA = scr + wave * 2 * kScr;
+    float* scrB = scrA + kScr;
+    const u4* isrc = reinterpret_cast<const u4*>(a.rimg + mp * (int64_t)nl * R::FLOATS);
+
+    for (int i = threadIdx.x; i < nl * ACC; i += NW * 64) accb[i] = 0;
+    for (int i = threadIdx.x; i < RU4; i += NW * 64) reinterpret_cast<u4*>(ring)[i] = isrc[i];
+    // power-of-two scale that brings max |g_lp| into [1, 2)
+    float sc = 1.f, isc = 1.f;
+    {
+        const float gm = __uint_as_float(*a.gmax);
+        if (gm > 0.f && gm < 3.0e38f) {
+            int e;
+            (void)frexpf(gm, &e);  // gm = f 2^e, f in [0.5, 1)
+            int k = 1 - e;
+            k = k > 120 ? 120 : (k < -120 ? -120 : k);
+            sc = ldexpf(1.f, k);
+            isc = ldexpf(1.f, -k);
+        }
+    }
+    __syncthreads();
+
+    const int64_t ntiles = (a.N + 15) >> 4;
+    const int64_t stride = (int64_t)gridDim.x * NW;
+    const int64_t iters = (ntiles + stride - 1) / stride;
+    const float* zb = a.z0 + m * a.N * D;
+    const float* glb = a.g_lp + m * a.N;
+    float* gzb = a.g_z ? a.g_z + m * a.N * D : nullptr;
+    float glp_acc = 0.f;
+    FxAcc fa{a.fx, 0.f};
+    int step = 0;
+    const int64_t nsteps = iters * nl;
+
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t tile = (it * gridDim.x + blockIdx.x) * NW + wave;
+        const int64_t row = tile * 16 + s;
+        const bool row_ok = row < a.N;
+        const int64_t rowc = row_ok ? row : a.N - 1;
+        f4 lo[HT], hi[HT], glo[HT], ghi[HT];
+        const float glp = row_ok ? sc * glb[rowc] : 0.f;
+        if (q == 0) glp_acc += glp;
+        {
+            const float* zr = zb + rowc * D + 4 * q;
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                lo[mm] = *reinterpret_cast<const f4*>(zr + 16 * mm);
+                hi[mm] = *reinterpret_cast<const f4*>(zr + H + 16 * mm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // d (-|z0|^2 / 2) / d z0, times g_log_prob
+                    glo[mm][j] = -glp * lo[mm][j];
+                    ghi[mm][j] = -glp * hi[mm][j];
+                }
+            }
+        }
+        const float gl = -glp;  // log_prob = base - sum of the layers' log-dets
+
+        for (int c = 0; c < nl; ++c, ++step) {
+            const float* img = ring + (step & 1) * R::FLOATS;
+            float* nxt = ring + ((step + 1) & 1) * R::FLOATS;
+            const bool more = (int64_t)step + 1 < nsteps;
+            u4 pf[NPF];
+            if (more) {
+                const u4* src = isrc + (int64_t)((c + 1 == nl) ? 0 : c + 1) * RU4;
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const int idx = threadIdx.x + i * NW * 64;
+                    pf[i] = src[idx < RU4 ? idx : 0];
+                }
+            }
+            int* acc = accb + c * ACC;
+            const float* fc = img + R::C_OFF;
+            if ((c & 1) == 0) {  // RealNVP(upper): conditioner = low half
+                layer_bwd16<H, L>(img, acc, fa, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
+                unfold_half<H, false>(fc, acc + P, fa, lane, 0, lo, glo);
+                unfold_half<H, false>(fc, acc + P, fa, lane, H, hi, ghi);
+            } else {             // RealNVP(lower) behind BatchNorm + Affine
+                layer_bwd16<H, L>(img, acc, fa, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
+                unfold_half<H, true>(fc, acc + P, fa, lane, 0, lo, glo);
+                unfold_half<H, true>(fc, acc + P, fa, lane, H, hi, ghi);
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const int idx = threadIdx.x + i * NW * 64;
+                    if (idx < RU4) reinterpret_cast<u4*>(nxt)[idx] = pf[i];
+                }
+            }
+            __syncthreads();
+        }
+        if (gzb && row_ok) {
+            float* gr = gzb + row * D + 4 * q;
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                f4 a0, a1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0[j] = glo[mm][j] * isc;
+                    a1[j] = ghi[mm][j] * isc;
+                }
+                *reinterpret_cast<f4*>(gr + 16 * mm) = a0;
+                *reinterpret_cast<f4*>(gr + H + 16 * mm) = a1;
+            }
+        }
+    }
+
+    // ---- flush: one global atomic per parameter per workgroup ----
+    // a term above the fixed-point budget may have wrapped an accumulator: poison the result instead of
+    // returning a wrong gradient (the budget is 2^13 per term in units where max |g_log_prob| is 1..2)
+    float amax = fa.amax;
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    float* red = scr;  // the transposition scratch is free now
+    __syncthreads();
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) amax = fmaxf(amax, red[w]);
+    const float poison = (amax * a.fx * (float)(iters * NW) >= 2147483648.f) ? __builtin_nanf("") : 0.f;
+    const float unfx = isc / a.fx;
+    float* gp = a.g_params + mp * a.gpstride;
+    float* gfo = a.g_fold + mp * (int64_t)nl * 2 * D;
+    for (int i = threadIdx.x; i < nl * ACC; i += NW * 64) {
+        const int c = i / ACC, k = i - c * ACC;
+        const float v = (float)accb[i] * unfx + poison;
+        if (k < P) atomicAdd(gp + (c >> 1) * a.stage + ((c & 1) ? a.low_off : 0) + k, v);
+        else if ((c & 1) && k < P + 2 * D) atomicAdd(gfo + (int64_t)c * 2 * D + (k - P), v);
+    }
+    {
+        float tot = glp_acc;
+        tot += __shfl_xor(tot, 1);
+        tot += __shfl_xor(tot, 2);
+        tot += __shfl_xor(tot, 4);
+        tot += __shfl_xor(tot, 8);
+        if (lane == 0) atomicAdd(a.glp_sum + mp, tot * isc);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int64_t rev_image_floats(int D, int L) {
+    const int H = D / 2, HT = (H + 15) / 16;
+    const int64_t f = (int64_t)(((H == 32) ? 4 : 2) + 2 * (L - 1) + 2 * HT) * 256 + (2 + 2 * (L - 1) + 2 * HT) * 16;
+    const int64_t b = (int64_t)(((H == 32) ? 4 : 2) + 2 * (L - 1) + 2 * HT) * 256;
+    return f + b + 4 * D;
+}
+
+constexpr int kRevNW = 8;
+
+static int64_t rev_lds_bytes(int D, int S, int L, int U) {
+    const int H = D / 2;
+    const int64_t P = 2 * (H * U + U) + (int64_t)(L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
+    const int64_t ACC = (P + 2 * D + 3) & ~3LL;
+    return (2 * rev_image_floats(D, L) + 2 * S * ACC + (int64_t)kRevNW * 2 * kScr) * 4;
+}
+
+int flow_train_rev_supported(int D, int S, int L, int U) {
+    if (!(D == 64 || D == 32) || L < 1 || L > 3 || U < 1 || U > 16 || S < 1) return 0;
+    return rev_lds_bytes(D, S, L, U) <= 160 * 1024 ? 1 : 0;
+}
+
+// workspace: [rimg | g_fold (Mp, 2S, 2, D) + glp_sum (Mp) + gmax (1)]; the tail is zeroed by the backward
+struct RevWs {
+    int64_t rimg, gfold, total;
+};
+static RevWs rev_ws(int64_t Mp, int D, int S, int L) {
+    RevWs w;
+    w.rimg = 0;
+    w.gfold = ((Mp * 2 * S * rev_image_floats(D, L) * 4 + 255) / 256) * 256;
+    w.total = w.gfold + ((Mp * 2 * S * 2 * D + Mp + 1) * 4 + 255) / 256 * 256;
+    return w;
+}
+int64_t flow_train_rev_workspace(int64_t Mp, int D, int S, int L) { return rev_ws(Mp, D, S, L).total; }
+
+template <int H, int L>
+static int launch_rev(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
+                      const float* g_lp, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int S, int U,
+                      int64_t pstride, int64_t gpstride, char* ws, hipStream_t st) {
+    constexpr int D = 2 * H;
+    typedef RevImage<H, L> R;
+    static_assert(R::FLOATS % 4 == 0, "image is copied in 16-byte units");
+    if (rev_image_floats(D, L) != R::FLOATS) return fail(TNF_ELAUNCH, "flow_bwd_f16: image size mismatch");
+    const RevWs w = rev_ws(Mp, D, S, L);
+    float* rimg = reinterpret_cast<float*>(ws + w.rimg);
+    float* gfold = reinterpret_cast<float*>(ws + w.gfold);
+    float* glp_sum = gfold + Mp * 2 * S * 2 * D;
+    unsigned* gmax = reinterpret_cast<unsigned*>(glp_sum + Mp);
+    if (hipMemsetAsync(gfold, 0, (size_t)(Mp * 2 * S * 2 * D + Mp + 1) * sizeof(float), st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "flow_bwd_f16: memset failed");
+    hipLaunchKernelGGL((flow_rev_images_kernel<H, L>), grid_xm(2 * S, Mp), dim3(64), 0, st, params, bn_mean, bn_alpha,
+                       rimg, S, U, pstride, Mp);
+    {
+        const int64_t n = M * N;
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_lp, n, gmax);
+    }
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const size_t smem = (size_t)rev_lds_bytes(D, S, L, U);
+    auto kern = flow_bwd_f16_kernel<H, L, kRevNW>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return fail(TNF_ELAUNCH, "flow_bwd_f16: cannot reserve %zu B of LDS", smem);
+    const int64_t ntiles = (N + 15) / 16;
+    int64_t bx = (ntiles + kRevNW - 1) / kRevNW;
+    int64_t cap = (256 + M - 1) / M;
+    if (bx > cap) bx = cap;
+    // an accumulator receives iters * NW terms per workgroup; allow 2^13 per term inside the int32 range
+    const int64_t adds = ((ntiles + bx * kRevNW - 1) / (bx * kRevNW)) * kRevNW;
+    int fbits = 31 - 13;
+    for (int64_t v = 1; v < adds; v <<= 1) --fbits;
+    if (fbits < 0) fbits = 0;
+    FlowBwdArgs a{z0, g_lp, rimg, gmax, g_z, g_params, gfold, glp_sum, M, Mp, N, gpstride, fl.stage, fl.p_up, S, U,
+                  ldexpf(1.f, fbits)};
+    hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(kRevNW * 64), smem, st, a);
+    int rc = check_launch("flow_bwd_f16");
+    if (rc) return rc;
+    return launch_flow_fold_backward(params, bn_alpha, gfold, glp_sum, g_params, Mp, D, S, L, U, pstride, gpstride, st);
+}
+
+int launch_flow_bwd_rev(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
+                        const float* g_lp, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S,
+                        int L, int U, int64_t pstride, int64_t gpstride, void* ws, hipStream_t st) {
+    if (!flow_train_rev_supported(D, S, L, U))
+        return fail(TNF_EUNSUPPORTED, "flow_bwd_f16: D=%d S=%d L=%d U=%d", D, S, L, U);
+    if (N <= 0) return TNF_OK;
+    char* wsb = reinterpret_cast<char*>(ws);
+#define TNF_REV(HH, LL) \
+    return launch_rev<HH, LL>(z0, params, bn_mean, bn_alpha, g_lp, g_z, g_params, M, Mp, N, S, U, pstride, gpstride, wsb, st)
+    if (D == 64) {
+        if (L == 1) TNF_REV(32, 1);
+        if (L == 2) TNF_REV(32, 2);
+        TNF_REV(32, 3);
+    }
+    if (L == 1) TNF_REV(16, 1);
+    if (L == 2) TNF_REV(16, 2);
+    TNF_REV(16, 3);
+#undef TNF_REV
+}
+
+}  // namespace tnf

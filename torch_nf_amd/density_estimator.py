@@ -348,6 +348,14 @@ class NormFlow(DensityEstimator):
             return self._core_log_prob(zc, params) - ld_support
         return self._core_log_prob(z, params)
 
+    def _train_path(self, z, params):
+        shape = (z.size(0), params.size(0), z.size(1), self.D, self.num_stages, self.num_layers, self.num_units)
+        if getattr(self, "reversible_training", True) and ops.flow_train_rev_supported(*shape):
+            return "reversible"
+        if ops.flow_train_supported(*shape):
+            return "layers"
+        return None
+
     def _core_log_prob(self, z, params):
         if self._ar_fused_ok(z, params):
             return ops.ar_flow_log_prob_raw(z, params, *self._ar_args())[0]
@@ -359,12 +367,12 @@ class NormFlow(DensityEstimator):
             return lp
         if (self.arch_type == "coupling" and z.dtype == torch.float32 and params.dtype == torch.float32
                 and z.dim() == 3 and z.size(0) == max(z.size(0), params.size(0))
-                and ops.flow_train_supported(z.size(0), params.size(0), z.size(1), self.D, self.num_stages,
-                                             self.num_layers, self.num_units)):
-            # training: fused per-layer kernels forward, MFMA backward kernels (BatchNorm stats constant)
+                and self._train_path(z, params) is not None):
+            # training (BatchNorm stats constant): the reversible pair -- whole-flow forward, one-kernel
+            # backward from z0 -- or, for the shapes it does not cover, one fused kernel per layer each way
             mean, alpha = self._bn_stats(_lib.require_device())
             return ops.flow_log_prob_train(z, params, mean, alpha, self.D, self.num_stages, self.num_layers,
-                                           self.num_units)
+                                           self.num_units, reversible=self._train_path(z, params) == "reversible")
         z0, sum_log_det = self._core_inverse(z, params)
         log_q = torch.sum(-(z0 ** 2), axis=2) / 2.0 - self.D * np.log(np.sqrt(2.0 * np.pi))
         return log_q - sum_log_det

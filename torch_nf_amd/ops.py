@@ -417,7 +417,57 @@ class _FlowLogProbFn(torch.autograd.Function):
             None, None, None, None
 
 
-def flow_log_prob_train(z, params, bn_mean, bn_alpha, D, S, L, U):
+def flow_train_rev_supported(M, Mp, N, D, S, L, U):
+    """The reversible pair: whole-flow forward that keeps only z0, one-kernel backward."""
+    return Mp in (1, M) and N >= 1 and lib.tnf_flow_train_rev_supported(D, S, L, U) == 1
+
+
+class _FlowLogProbRevFn(torch.autograd.Function):
+    """log_prob through the whole-flow kernel (tnf_flow_log_prob_fwd_rev_f32); the backward rebuilds every
+    layer's input from z0 inside one kernel (tnf_flow_log_prob_bwd_rev_f32), so no activations are kept."""
+
+    @staticmethod
+    def forward(ctx, z, params, bn_mean, bn_alpha, D, S, L, U):
+        dev = _lib.require_device()
+        zc = _stage(z.detach(), dev)
+        pc, pstride = _rows(params.detach(), dev)
+        mean_c, alpha_c = _stats(bn_mean, dev), _stats(bn_alpha, dev)
+        M, N = zc.shape[0], zc.shape[1]
+        Mp = pc.shape[0]
+        lp = torch.empty((M, N), dtype=torch.float32, device=dev)
+        z0 = torch.empty_like(zc)
+        check(lib.tnf_flow_log_prob_fwd_rev_f32(zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+                                                lp.data_ptr(), z0.data_ptr(), M, Mp, N, D, S, L, U, pstride,
+                                                _lib.stream_ptr()))
+        ctx.save_for_backward(z0, pc, mean_c, alpha_c)
+        ctx.cfg = (D, S, L, U, pstride, z.device, params.device, tuple(params.shape))
+        return lp if z.device == dev else lp.to(z.device)
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        z0, pc, mean_c, alpha_c = ctx.saved_tensors
+        D, S, L, U, pstride, z_home, p_home, p_shape = ctx.cfg
+        dev = z0.device
+        M, N = z0.shape[0], z0.shape[1]
+        Mp = pc.shape[0]
+        g = _stage(g_lp.float(), dev)
+        gz = torch.empty_like(z0) if ctx.needs_input_grad[0] else None
+        gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+        ws_bytes = check(lib.tnf_flow_train_rev_workspace_bytes(Mp, D, S, L, U))
+        ws = _workspace(ws_bytes, dev)
+        check(lib.tnf_flow_log_prob_bwd_rev_f32(z0.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+                                                g.data_ptr(), gz.data_ptr() if gz is not None else None,
+                                                gp.data_ptr(), M, Mp, N, D, S, L, U, pstride, gp.shape[1],
+                                                ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        if gz is not None and z_home != dev:
+            gz = gz.to(z_home)
+        return gz, (gp if p_home == dev else gp.to(p_home)), None, None, None, None, None, None
+
+
+def flow_log_prob_train(z, params, bn_mean, bn_alpha, D, S, L, U, reversible=True):
+    M, Mp, N = z.shape[0], (params.shape[0] if params.dim() > 1 else 1), z.shape[1]
+    if reversible and flow_train_rev_supported(M, Mp, N, D, S, L, U):
+        return _FlowLogProbRevFn.apply(z, params, bn_mean, bn_alpha, D, S, L, U)
     return _FlowLogProbFn.apply(z, params, bn_mean, bn_alpha, D, S, L, U)
 
 
