@@ -18,8 +18,7 @@
 // the scale comes out again when the gradients leave the kernel.
 //
 // A wave carries one 16-sample tile through all 2S layers, so the per-layer gradient accumulators
-// cannot live in registers: they are ds_add_f32 targets in LDS (packed like the layer's parameter
-// block, 2S x ~10 KB) and leave with one global atomic per parameter per workgroup.  That leaves
+// cannot live in registers: they are fixed-point ds_add_u32 targets in LDS (AccLayout, 2S x ~11.5 KB) and leave with one global atomic per parameter per workgroup.  That leaves
 // no room for all layers' operand images, so the waves of a workgroup step through the layers
 // together: the next layer's image (forward operands | transposed operands | fold constants,
 // ~21 KB, built once per call by flow_rev_images_kernel) is prefetched into registers during a
@@ -163,10 +162,16 @@ flow_rev_images_kernel(const float* __restrict__ params, const float* __restrict
 
 __global__ void __launch_bounds__(256)
 flow_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ out) {
+    __shared__ float red[4];
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));  // one atomic per block: they serialise on the one word
+    }
 }
 
 // acc layout (lane (s, q), reg j = row 4q + j, col s)  ->  operand layout with K = samples:
@@ -204,29 +209,48 @@ __device__ __forceinline__ f4 mm3(h4 wh, h4 wl, h4 xh, h4 xl, f4 acc) {
     return mfma16h(wl, xh, acc);
 }
 // LDS accumulators are 32-bit FIXED POINT (value * fx): on gfx950 ds_add_f32 costs ~190 cycles per
-// wave-instruction, ds_add_u32 ~4 (scratch/lds_atomic_bench.hip), and a wave's 16-sample tile needs ~70 of them
+// wave-instruction, ds_add_u32 ~4 (scratch/lds_atomic_bench.hip), and a wave's 16-sample tile needs ~60 of them
 // per layer.  fx is chosen on the host so that 2^13 per accumulated term cannot overflow (see launch_rev);
 // amax tracks the largest term so the kernel can tell when that budget did not hold.
+//
+// Accumulator layout of one layer (ints), hidden width padded to 16 and rows padded to an odd stride so that
+// the 64 lanes of a tile add without masks and with at most 2-way bank conflicts:
+//   W0 [net][f < H][17] | b0 [net][16] | { Wh [net][k_in < 16][17] | bh [net][16] } x (L-1) |
+//   W2 [net][k < 16][H+1] | b2 [net][H] | fold dA [D] | fold dB [D]
+template <int H, int L>
+struct AccLayout {
+    static constexpr int US = 17, HS = H + 1;
+    static constexpr int o_w0 = 0;
+    static constexpr int o_b0 = o_w0 + 2 * H * US;
+    static constexpr int o_h = o_b0 + 32;
+    static constexpr int HID = 2 * 16 * US + 32;
+    static constexpr int o_w2 = o_h + (L - 1) * HID;
+    static constexpr int o_b2 = o_w2 + 2 * 16 * HS;
+    static constexpr int o_fold = o_b2 + 2 * H;
+    static constexpr int INTS = (o_fold + 4 * H + 3) & ~3;
+};
+
 struct FxAcc {
     float fx;    // scale
     float amax;  // largest |term| seen by this lane
 };
-__device__ __forceinline__ void lds_add1(int* p, float v, FxAcc& fa) {
-    fa.amax = fmaxf(fa.amax, fabsf(v));
-    atomicAdd(p, __float2int_rn(v * fa.fx));
+__device__ __forceinline__ int fx_cvt(float v, float fx) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v * fx));  // floor(x + 0.5), saturating
+    return r;
 }
-__device__ __forceinline__ void lds_add4(int* p, f4 v, int ncol, FxAcc& fa) {  // columns 0..ncol-1 of this lane's 4 are real
+// all four values of every lane are real (padded entries receive exact zeros)
+__device__ __forceinline__ void lds_add4(int* p, f4 v, FxAcc& fa) {
+    fa.amax = fmaxf(fa.amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    fa.amax = fmaxf(fa.amax, fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j < ncol) lds_add1(p + j, v[j], fa);
+    for (int j = 0; j < 4; ++j) atomicAdd(p + j, fx_cvt(v[j], fa.fx));
 }
-// sum over the 16 sample lanes of a q-group (DPP row rotations), result in every lane
-__device__ __forceinline__ float rowsum_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    return v;
+// a row-sum tile holds the same four sums (rows 4q + j) in every sample lane: lanes s < 4 add row 4q + s
+__device__ __forceinline__ void lds_add_rows(int* p4q, f4 v, int s, FxAcc& fa) {
+    const float t = (s & 2) ? ((s & 1) ? v[3] : v[2]) : ((s & 1) ? v[1] : v[0]);
+    fa.amax = fmaxf(fa.amax, fabsf(t));
+    if (s < 4) atomicAdd(p4q + s, fx_cvt(t, fa.fx));
 }
 
 struct FlowBwdArgs {
@@ -265,8 +289,7 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         lo = __builtin_bit_cast(h4, u2{wv[2], wv[3]});
     };
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
-    const int ncol = (U - 4 * q) < 0 ? 0 : ((U - 4 * q) > 4 ? 4 : (U - 4 * q));  // real units among 4q .. 4q+3
-    const bool row_u = s < U;
+    typedef AccLayout<H, L> A_;
 
     // ---- 1. forward recompute ----
     f4 r[L][2];
@@ -331,11 +354,6 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         }
     }
 
-    // packed accumulator offsets (the layer's parameter block, bijectors.py:222-235)
-    const int o_w0 = 0, o_b0 = 2 * H * U;
-    const int o_h = o_b0 + 2 * U;                 // + l * (2 U U + 2 U)
-    const int o_w2 = o_h + (L - 1) * (2 * U * U + 2 * U), o_b2 = o_w2 + 2 * U * H;
-
     // ---- 3. output layer: dW2, db2, d h_{L-1} ----
     f4 dh[2];
 #pragma unroll
@@ -348,9 +366,8 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         for (int mo = 0; mo < HT; ++mo) {
             const T16 d_t = tsplit(dout[net][mo], scrA, lane);
             const f4 dw = outer16h(d_t, h_t);  // [o = 16 mo + 4q + j][k = s]
-            if (row_u) lds_add4(acc + o_w2 + net * U * H + s * H + 16 * mo + 4 * q, dw, 4, fa);
-            const f4 db = rowsum16h(d_t);
-            if (s == 0) lds_add4(acc + o_b2 + net * H + 16 * mo + 4 * q, db, 4, fa);
+            lds_add4(acc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mo + 4 * q, dw, fa);
+            lds_add_rows(acc + A_::o_b2 + net * H + 16 * mo + 4 * q, rowsum16h(d_t), s, fa);
         }
         if constexpr (H == 32) {
             u4 a_, b_;
@@ -386,10 +403,9 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
             const T16 d_t = tsplit(da, scrA, lane);
             const T16 h_t = tsplit(hprev, scrB, lane);
             const f4 dw = outer16h(d_t, h_t);  // [k_out = 4q + j][k_in = s]
-            int* ah = acc + o_h + l * (2 * U * U + 2 * U);
-            if (row_u) lds_add4(ah + net * U * U + s * U + 4 * q, dw, ncol, fa);
-            const f4 db = rowsum16h(d_t);
-            if (s == 0) lds_add4(ah + 2 * U * U + net * U + 4 * q, db, ncol, fa);
+            int* ah = acc + A_::o_h + l * A_::HID;
+            lds_add4(ah + (net * 16 + s) * A_::US + 4 * q, dw, fa);
+            lds_add_rows(ah + 2 * 16 * A_::US + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
             h4 dhi, dlo, wh, wl;
             split4(da, dhi, dlo);
             hl(bg, BImg::g_wh(l, net), wh, wl);
@@ -408,14 +424,13 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
             da[j] = dh[net][j] * (4.f * rr * (1.f - rr));
         }
         const T16 d_t = tsplit(da, scrA, lane);
-        const f4 db = rowsum16h(d_t);
-        if (s == 0) lds_add4(acc + o_b0 + net * U + 4 * q, db, ncol, fa);
+        lds_add_rows(acc + A_::o_b0 + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
         h4 dhi, dlo;
         split4(da, dhi, dlo);
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
             const f4 dw = outer16h(d_t, x_t[mm]);  // [u = 4q + j][f = 16 mm + s]
-            lds_add4(acc + o_w0 + net * H * U + (16 * mm + s) * U + 4 * q, dw, ncol, fa);
+            lds_add4(acc + A_::o_w0 + (net * H + 16 * mm + s) * A_::US + 4 * q, dw, fa);
             h4 wh, wl;
             hl(bg, BImg::g_w0(net, mm), wh, wl);
             gx[mm] = mm3(wh, wl, dhi, dlo, gx[mm]);
@@ -424,10 +439,12 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
 }
 
 // Undo the fold in front of a layer on one half (features f0 + 16 mm + 4q + j): v <- (v - B)/A, g <- g A;
-// with AFFINE the tile's contributions to dA, dB go to the accumulators behind the layer's parameters.
+// with AFFINE the tile's contributions to dA = sum g v, dB = sum g go to gf: the two tiles are transposed
+// through the scratch so that a lane holds four samples of one feature, summed in the lane, and the four
+// lanes that share a feature add to the same accumulator word.
 template <int H, bool AFFINE>
-__device__ __forceinline__ void unfold_half(const float* fc, int* gf, FxAcc& fa, int lane, int f0,
-                                            f4 (&v)[(H + 15) / 16], f4 (&g)[(H + 15) / 16]) {
+__device__ __forceinline__ void unfold_half(const float* fc, int* gf, FxAcc& fa, float* scrA, float* scrB, int lane,
+                                            int f0, f4 (&v)[(H + 15) / 16], f4 (&g)[(H + 15) / 16]) {
     constexpr int D = 2 * H;
     constexpr int HT = (H + 15) / 16;
     const int s = lane & 15, q = lane >> 4;
@@ -437,18 +454,23 @@ __device__ __forceinline__ void unfold_half(const float* fc, int* gf, FxAcc& fa,
         const f4 A = *reinterpret_cast<const f4*>(fc + f);
         const f4 iA = *reinterpret_cast<const f4*>(fc + 2 * D + f);
         const f4 C = *reinterpret_cast<const f4*>(fc + 3 * D + f);
+        f4 vp, gv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float vp = __builtin_fmaf(v[mm][j], iA[j], C[j]);
-            if (AFFINE) {
-                const float da = rowsum_dpp(g[mm][j] * vp), db = rowsum_dpp(g[mm][j]);
-                if (s == 0) {
-                    lds_add1(gf + f + j, da, fa);
-                    lds_add1(gf + D + f + j, db, fa);
-                }
-            }
+            vp[j] = __builtin_fmaf(v[mm][j], iA[j], C[j]);
+            gv[j] = g[mm][j] * vp[j];
+        }
+        if (AFFINE) {
+            const f4 ta = transpose16(gv, scrA, lane), tb = transpose16(g[mm], scrB, lane);
+            const float da = (ta[0] + ta[1]) + (ta[2] + ta[3]), db = (tb[0] + tb[1]) + (tb[2] + tb[3]);
+            fa.amax = fmaxf(fa.amax, fmaxf(fabsf(da), fabsf(db)));
+            atomicAdd(gf + f0 + 16 * mm + s, fx_cvt(da, fa.fx));       // feature = row s of the transposed tile
+            atomicAdd(gf + D + f0 + 16 * mm + s, fx_cvt(db, fa.fx));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
             g[mm][j] *= A[j];
-            v[mm][j] = vp;
+            v[mm][j] = vp[j];
         }
     }
 }
@@ -464,8 +486,8 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nl = 2 * a.S;
     const int U = a.U;
-    const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
-    const int ACC = (P + 2 * D + 3) & ~3;
+    typedef AccLayout<H, L> A_;
+    constexpr int ACC = A_::INTS;
     float* ring = lds;                          // [2][R::FLOATS]
     int* accb = reinterpret_cast<int*>(lds + 2 * R::FLOATS);  // [nl][ACC] fixed point
     float* scr = lds + 2 * R::FLOATS + nl * ACC;              // [NW][2][kScr]
@@ -547,12 +569,12 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
             const float* fc = img + R::C_OFF;
             if ((c & 1) == 0) {  // RealNVP(upper): conditioner = low half
                 layer_bwd16<H, L>(img, acc, fa, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
-                unfold_half<H, false>(fc, acc + P, fa, lane, 0, lo, glo);
-                unfold_half<H, false>(fc, acc + P, fa, lane, H, hi, ghi);
+                unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
+                unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             } else {             // RealNVP(lower) behind BatchNorm + Affine
                 layer_bwd16<H, L>(img, acc, fa, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
-                unfold_half<H, true>(fc, acc + P, fa, lane, 0, lo, glo);
-                unfold_half<H, true>(fc, acc + P, fa, lane, H, hi, ghi);
+                unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
+                unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             }
             if (more) {
 #pragma unroll
@@ -594,11 +616,42 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
     const float unfx = isc / a.fx;
     float* gp = a.g_params + mp * a.gpstride;
     float* gfo = a.g_fold + mp * (int64_t)nl * 2 * D;
-    for (int i = threadIdx.x; i < nl * ACC; i += NW * 64) {
-        const int c = i / ACC, k = i - c * ACC;
-        const float v = (float)accb[i] * unfx + poison;
+    // walk the layer's parameter block (bijectors.py:222-235: per MLP layer [W_t | W_s | b_t | b_s], W[in][out])
+    const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
+    for (int i = threadIdx.x; i < nl * (P + 2 * D); i += NW * 64) {
+        const int c = i / (P + 2 * D);
+        int k = i - c * (P + 2 * D);
+        const int* acc = accb + c * ACC;
+        int src;
+        if (k >= P) {
+            if (!(c & 1)) continue;
+            src = A_::o_fold + (k - P);
+        } else {
+            int kk = k;
+            if (kk < 2 * H * U + 2 * U) {
+                if (kk < 2 * H * U) src = A_::o_w0 + (kk / U) * A_::US + kk % U;   // (net, f) rows are contiguous
+                else src = A_::o_b0 + ((kk - 2 * H * U) / U) * 16 + (kk - 2 * H * U) % U;
+            } else {
+                kk -= 2 * H * U + 2 * U;
+                const int hs = 2 * U * U + 2 * U;
+                if (kk < (L - 1) * hs) {
+                    const int l = kk / hs, r = kk - l * hs;
+                    if (r < 2 * U * U) {
+                        const int net = r / (U * U), rr = r - net * U * U;
+                        src = A_::o_h + l * A_::HID + (net * 16 + rr / U) * A_::US + rr % U;
+                    } else src = A_::o_h + l * A_::HID + 2 * 16 * A_::US + ((r - 2 * U * U) / U) * 16 + (r - 2 * U * U) % U;
+                } else {
+                    kk -= (L - 1) * hs;
+                    if (kk < 2 * U * H) {
+                        const int net = kk / (U * H), rr = kk - net * U * H;
+                        src = A_::o_w2 + (net * 16 + rr / H) * A_::HS + rr % H;
+                    } else src = A_::o_b2 + (kk - 2 * U * H);
+                }
+            }
+        }
+        const float v = (float)acc[src] * unfx + poison;
         if (k < P) atomicAdd(gp + (c >> 1) * a.stage + ((c & 1) ? a.low_off : 0) + k, v);
-        else if ((c & 1) && k < P + 2 * D) atomicAdd(gfo + (int64_t)c * 2 * D + (k - P), v);
+        else atomicAdd(gfo + (int64_t)c * 2 * D + (k - P), v);
     }
     {
         float tot = glp_acc;
@@ -624,8 +677,8 @@ constexpr int kRevNW = 8;
 
 static int64_t rev_lds_bytes(int D, int S, int L, int U) {
     const int H = D / 2;
-    const int64_t P = 2 * (H * U + U) + (int64_t)(L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
-    const int64_t ACC = (P + 2 * D + 3) & ~3LL;
+    const int64_t ACC = (2 * H * 17 + 32 + (int64_t)(L - 1) * (2 * 16 * 17 + 32) + 2 * 16 * (H + 1) + 2 * H + 4 * H + 3) & ~3LL;
+    (void)U;
     return (2 * rev_image_floats(D, L) + 2 * S * ACC + (int64_t)kRevNW * 2 * kScr) * 4;
 }
 
@@ -655,6 +708,8 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     typedef RevImage<H, L> R;
     static_assert(R::FLOATS % 4 == 0, "image is copied in 16-byte units");
     if (rev_image_floats(D, L) != R::FLOATS) return fail(TNF_ELAUNCH, "flow_bwd_f16: image size mismatch");
+    if (rev_lds_bytes(D, S, L, U) != (2 * (int64_t)R::FLOATS + 2 * S * (int64_t)AccLayout<H, L>::INTS + (int64_t)kRevNW * 2 * kScr) * 4)
+        return fail(TNF_ELAUNCH, "flow_bwd_f16: LDS size mismatch");
     const RevWs w = rev_ws(Mp, D, S, L);
     float* rimg = reinterpret_cast<float*>(ws + w.rimg);
     float* gfold = reinterpret_cast<float*>(ws + w.gfold);
@@ -667,7 +722,7 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     {
         const int64_t n = M * N;
         int64_t blocks = (n + 255) / 256;
-        if (blocks > 1024) blocks = 1024;
+        if (blocks > 256) blocks = 256;
         hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_lp, n, gmax);
     }
     const FlowLayout fl = flow_layout(D, S, L, U);
