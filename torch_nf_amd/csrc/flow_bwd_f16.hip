@@ -232,25 +232,35 @@ struct AccLayout {
 
 struct FxAcc {
     float fx;    // scale
-    float amax;  // largest |term| seen by this lane
+    float amax;  // largest |term * fx| seen by this lane
 };
-__device__ __forceinline__ int fx_cvt(float v, float fx) {
+// max(m, |a|, |b|) in one instruction.  a and b must be results of ordinary VALU instructions: the compiler does
+// not see inside the asm, so it would not insert the wait states an MFMA result needs before a VALU reads it.
+__device__ __forceinline__ float amax3(float m, float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int fx_cvt(float scaled) {
     int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v * fx));  // floor(x + 0.5), saturating
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(scaled));  // floor(x + 0.5), saturating
     return r;
 }
 // all four values of every lane are real (padded entries receive exact zeros)
 __device__ __forceinline__ void lds_add4(int* p, f4 v, FxAcc& fa) {
-    fa.amax = fmaxf(fa.amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
-    fa.amax = fmaxf(fa.amax, fmaxf(fabsf(v[2]), fabsf(v[3])));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(p + j, fx_cvt(v[j], fa.fx));
+    const float t0 = v[0] * fa.fx, t1 = v[1] * fa.fx, t2 = v[2] * fa.fx, t3 = v[3] * fa.fx;
+    fa.amax = amax3(fa.amax, t0, t1);
+    fa.amax = amax3(fa.amax, t2, t3);
+    atomicAdd(p + 0, fx_cvt(t0));
+    atomicAdd(p + 1, fx_cvt(t1));
+    atomicAdd(p + 2, fx_cvt(t2));
+    atomicAdd(p + 3, fx_cvt(t3));
 }
 // a row-sum tile holds the same four sums (rows 4q + j) in every sample lane: lanes s < 4 add row 4q + s
 __device__ __forceinline__ void lds_add_rows(int* p4q, f4 v, int s, FxAcc& fa) {
-    const float t = (s & 2) ? ((s & 1) ? v[3] : v[2]) : ((s & 1) ? v[1] : v[0]);
+    const float t = ((s & 2) ? ((s & 1) ? v[3] : v[2]) : ((s & 1) ? v[1] : v[0])) * fa.fx;
     fa.amax = fmaxf(fa.amax, fabsf(t));
-    if (s < 4) atomicAdd(p4q + s, fx_cvt(t, fa.fx));
+    if (s < 4) atomicAdd(p4q + s, fx_cvt(t));
 }
 
 struct FlowBwdArgs {
@@ -270,7 +280,9 @@ struct FlowBwdArgs {
 // One coupling layer backwards on one tile.  x: conditioner half (= layer input and output);
 // y: in = transformed half of the OUTPUT, out = of the INPUT;  gx, gy: in = gradients wrt the layer's
 // outputs, out = wrt its inputs;  gl = d loss / d (sum of s) for this sample (natural log units).
-template <int H, int L>
+// SPARE (num_units <= 15): hidden unit 15 is padding, so the transposed activation operand carries a row of
+// ones there and the bias gradients of the layers behind a tanh arrive as column 15 of the weight-gradient tiles.
+template <int H, int L, bool SPARE>
 __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& fa, float* scrA, float* scrB, int lane, int U,
                                             const f4 (&x)[(H + 15) / 16], f4 (&y)[(H + 15) / 16],
                                             f4 (&gx)[(H + 15) / 16], f4 (&gy)[(H + 15) / 16], float gl) {
@@ -291,8 +303,8 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     typedef AccLayout<H, L> A_;
 
-    // ---- 1. forward recompute ----
-    f4 r[L][2];
+    // ---- 1. forward recompute (h = tanh = 1 - 2r is what the backward needs: tanh' = 1 - h^2) ----
+    f4 r[L][2], h[L][2];
     if constexpr (H == 32) {
         u4 a_, b_;
         split2(x[0][0], x[0][1], a_[0], b_[0]);
@@ -328,6 +340,16 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
             hl(fg, FImg::g_wh(l, net), wh, wl);
             r[l + 1][net] = sig2_4(mm3(wh, wl, rh, rl, bias(FImg::b_bh(l, net))));
         }
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int net = 0; net < 2; ++net)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[l][net][j] = __builtin_fmaf(-2.f, r[l][net][j], 1.f);
+    auto with_ones = [&](f4 v) -> f4 {  // unit 15 lives in lane group q = 3, register 3
+        if (SPARE) v[3] = (q == 3) ? 1.f : v[3];
+        return v;
+    };
     f4 dout[2][HT];
     {
         h4 rh[2], rl[2];
@@ -358,16 +380,13 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
     f4 dh[2];
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
-        f4 hcur;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hcur[j] = __builtin_fmaf(-2.f, r[L - 1][net][j], 1.f);
-        const T16 h_t = tsplit(hcur, scrB, lane);
+        const T16 h_t = tsplit(with_ones(h[L - 1][net]), scrB, lane);
 #pragma unroll
         for (int mo = 0; mo < HT; ++mo) {
             const T16 d_t = tsplit(dout[net][mo], scrA, lane);
             const f4 dw = outer16h(d_t, h_t);  // [o = 16 mo + 4q + j][k = s]
             lds_add4(acc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mo + 4 * q, dw, fa);
-            lds_add_rows(acc + A_::o_b2 + net * H + 16 * mo + 4 * q, rowsum16h(d_t), s, fa);
+            if (!SPARE) lds_add_rows(acc + A_::o_b2 + net * H + 16 * mo + 4 * q, rowsum16h(d_t), s, fa);
         }
         if constexpr (H == 32) {
             u4 a_, b_;
@@ -393,19 +412,18 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
     for (int l = L - 2; l >= 0; --l)
 #pragma unroll
         for (int net = 0; net < 2; ++net) {
-            f4 da, hprev;
+            f4 da;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float rr = r[l + 1][net][j];
-                da[j] = dh[net][j] * (4.f * rr * (1.f - rr));
-                hprev[j] = __builtin_fmaf(-2.f, r[l][net][j], 1.f);
+                const float hh = h[l + 1][net][j];
+                da[j] = dh[net][j] * __builtin_fmaf(-hh, hh, 1.f);
             }
             const T16 d_t = tsplit(da, scrA, lane);
-            const T16 h_t = tsplit(hprev, scrB, lane);
+            const T16 h_t = tsplit(with_ones(h[l][net]), scrB, lane);
             const f4 dw = outer16h(d_t, h_t);  // [k_out = 4q + j][k_in = s]
             int* ah = acc + A_::o_h + l * A_::HID;
             lds_add4(ah + (net * 16 + s) * A_::US + 4 * q, dw, fa);
-            lds_add_rows(ah + 2 * 16 * A_::US + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
+            if (!SPARE) lds_add_rows(ah + 2 * 16 * A_::US + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
             h4 dhi, dlo, wh, wl;
             split4(da, dhi, dlo);
             hl(bg, BImg::g_wh(l, net), wh, wl);
@@ -420,8 +438,8 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         f4 da;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float rr = r[0][net][j];
-            da[j] = dh[net][j] * (4.f * rr * (1.f - rr));
+            const float hh = h[0][net][j];
+            da[j] = dh[net][j] * __builtin_fmaf(-hh, hh, 1.f);
         }
         const T16 d_t = tsplit(da, scrA, lane);
         lds_add_rows(acc + A_::o_b0 + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
@@ -462,10 +480,10 @@ __device__ __forceinline__ void unfold_half(const float* fc, int* gf, FxAcc& fa,
         }
         if (AFFINE) {
             const f4 ta = transpose16(gv, scrA, lane), tb = transpose16(g[mm], scrB, lane);
-            const float da = (ta[0] + ta[1]) + (ta[2] + ta[3]), db = (tb[0] + tb[1]) + (tb[2] + tb[3]);
-            fa.amax = fmaxf(fa.amax, fmaxf(fabsf(da), fabsf(db)));
-            atomicAdd(gf + f0 + 16 * mm + s, fx_cvt(da, fa.fx));       // feature = row s of the transposed tile
-            atomicAdd(gf + D + f0 + 16 * mm + s, fx_cvt(db, fa.fx));
+            const float da = ((ta[0] + ta[1]) + (ta[2] + ta[3])) * fa.fx, db = ((tb[0] + tb[1]) + (tb[2] + tb[3])) * fa.fx;
+            fa.amax = amax3(fa.amax, da, db);
+            atomicAdd(gf + f0 + 16 * mm + s, fx_cvt(da));       // feature = row s of the transposed tile
+            atomicAdd(gf + D + f0 + 16 * mm + s, fx_cvt(db));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -475,7 +493,7 @@ __device__ __forceinline__ void unfold_half(const float* fc, int* gf, FxAcc& fa,
     }
 }
 
-template <int H, int L, int NW>
+template <int H, int L, int NW, bool SPARE>
 __global__ void __launch_bounds__(NW * 64)
 flow_bwd_f16_kernel(FlowBwdArgs a) {
     typedef RevImage<H, L> R;
@@ -568,11 +586,11 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
             int* acc = accb + c * ACC;
             const float* fc = img + R::C_OFF;
             if ((c & 1) == 0) {  // RealNVP(upper): conditioner = low half
-                layer_bwd16<H, L>(img, acc, fa, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
+                layer_bwd16<H, L, SPARE>(img, acc, fa, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
                 unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
                 unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             } else {             // RealNVP(lower) behind BatchNorm + Affine
-                layer_bwd16<H, L>(img, acc, fa, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
+                layer_bwd16<H, L, SPARE>(img, acc, fa, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             }
@@ -612,7 +630,7 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < NW; ++w) amax = fmaxf(amax, red[w]);
-    const float poison = (amax * a.fx * (float)(iters * NW) >= 2147483648.f) ? __builtin_nanf("") : 0.f;
+    const float poison = (amax * (float)(iters * NW) >= 2147483648.f) ? __builtin_nanf("") : 0.f;
     const float unfx = isc / a.fx;
     float* gp = a.g_params + mp * a.gpstride;
     float* gfo = a.g_fold + mp * (int64_t)nl * 2 * D;
@@ -639,13 +657,15 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
                     if (r < 2 * U * U) {
                         const int net = r / (U * U), rr = r - net * U * U;
                         src = A_::o_h + l * A_::HID + (net * 16 + rr / U) * A_::US + rr % U;
-                    } else src = A_::o_h + l * A_::HID + 2 * 16 * A_::US + ((r - 2 * U * U) / U) * 16 + (r - 2 * U * U) % U;
+                    } else if (SPARE) src = A_::o_h + l * A_::HID + (((r - 2 * U * U) / U) * 16 + 15) * A_::US + (r - 2 * U * U) % U;
+                    else src = A_::o_h + l * A_::HID + 2 * 16 * A_::US + ((r - 2 * U * U) / U) * 16 + (r - 2 * U * U) % U;
                 } else {
                     kk -= (L - 1) * hs;
                     if (kk < 2 * U * H) {
                         const int net = kk / (U * H), rr = kk - net * U * H;
                         src = A_::o_w2 + (net * 16 + rr / H) * A_::HS + rr % H;
-                    } else src = A_::o_b2 + (kk - 2 * U * H);
+                    } else if (SPARE) src = A_::o_w2 + (((kk - 2 * U * H) / H) * 16 + 15) * A_::HS + (kk - 2 * U * H) % H;
+                    else src = A_::o_b2 + (kk - 2 * U * H);
                 }
             }
         }
@@ -727,7 +747,7 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     }
     const FlowLayout fl = flow_layout(D, S, L, U);
     const size_t smem = (size_t)rev_lds_bytes(D, S, L, U);
-    auto kern = flow_bwd_f16_kernel<H, L, kRevNW>;
+    auto kern = U <= 15 ? flow_bwd_f16_kernel<H, L, kRevNW, true> : flow_bwd_f16_kernel<H, L, kRevNW, false>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: cannot reserve %zu B of LDS", smem);
     const int64_t ntiles = (N + 15) / 16;
