@@ -68,7 +68,8 @@ def test_cond_flow_log_prob(tnf, oracle, D, S, L, U, Dx, hidden, M, variant):
     lp_o = _oracle_lp(oracle, nf, cde, z, x)
     # north_star tolerance: log_prob rtol <= 1e-5 against the reference's CPU path
     torch.testing.assert_close(lp_f.cpu(), lp_o, rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(lp_f, lp_m, rtol=1e-5, atol=1e-5)
+    # the two GPU paths are each within 1e-5 of the oracle, hence within 2e-5 of one another
+    torch.testing.assert_close(lp_f, lp_m, rtol=2e-5, atol=2e-5)
 
 
 def test_cond_flow_outputs_and_selection(tnf, oracle):
