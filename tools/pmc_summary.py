@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(out, "p*", "**", "*kernel_trace.csv"), recursive
         dur[name].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 res = {}
 for name, ctr in acc.items():
-    if not any(t in name for t in ("flow_fused", "coupling_mfma", "cond_flow", "cond_gw", "maf_kernel", "to_interval")):
+    if not any(t in name for t in ("flow_fused", "flow_bwd", "coupling_mfma", "coupling_bwd", "cond_flow", "cond_gw", "maf_kernel", "to_interval")):
         continue
     # steady-state dispatches only: drop the first (cold) one of each counter
     res[name] = {k: sum(v[1:]) / max(1, len(v) - 1) if len(v) > 1 else v[0] for k, v in ctr.items()}

@@ -28,6 +28,15 @@
 
 namespace tnf {
 
+#ifndef TNF_REV_NW
+#define TNF_REV_NW 12
+#endif
+#ifndef TNF_REV_NSCR
+#define TNF_REV_NSCR 1
+#endif
+constexpr int kRevNW = TNF_REV_NW;
+constexpr int kRevNScr = TNF_REV_NSCR;  // transposition scratch tiles per wave (1: both operands share one, LDS ops are in order)
+
 // Transposed raw weights as split-f16 A operands, lane (r = lane&15, q = lane>>4), 16 B per lane per group:
 //   W2 (d h_last[k] = sum_o W2[k][o] d out[o]):  m = k = r.  H = 32: K slot (q, i) is o = 16 (i>>2) + 4q + (i&3),
 //       one group of 8 hi + one of 8 lo per net;  H = 16: K = o = 4q + j, one group [hi(4) | lo(4)] per net.
@@ -515,8 +524,8 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
     const int64_t m = grid_m();
     if (m >= a.M) return;
     const int64_t mp = a.Mp == 1 ? 0 : m;
-    float* scrA = scr + wave * 2 * kScr;
-    float* scrB = scrA + kScr;
+    float* scrA = scr + wave * kRevNScr * kScr;
+    float* scrB = scrA + (kRevNScr - 1) * kScr;
     const u4* isrc = reinterpret_cast<const u4*>(a.rimg + mp * (int64_t)nl * R::FLOATS);
 
     for (int i = threadIdx.x; i < nl * ACC; i += NW * 64) accb[i] = 0;
@@ -693,13 +702,13 @@ static int64_t rev_image_floats(int D, int L) {
     return f + b + 4 * D;
 }
 
-constexpr int kRevNW = 8;
+
 
 static int64_t rev_lds_bytes(int D, int S, int L, int U) {
     const int H = D / 2;
     const int64_t ACC = (2 * H * 17 + 32 + (int64_t)(L - 1) * (2 * 16 * 17 + 32) + 2 * 16 * (H + 1) + 2 * H + 4 * H + 3) & ~3LL;
     (void)U;
-    return (2 * rev_image_floats(D, L) + 2 * S * ACC + (int64_t)kRevNW * 2 * kScr) * 4;
+    return (2 * rev_image_floats(D, L) + 2 * S * ACC + (int64_t)kRevNW * kRevNScr * kScr) * 4;
 }
 
 int flow_train_rev_supported(int D, int S, int L, int U) {
@@ -728,7 +737,7 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     typedef RevImage<H, L> R;
     static_assert(R::FLOATS % 4 == 0, "image is copied in 16-byte units");
     if (rev_image_floats(D, L) != R::FLOATS) return fail(TNF_ELAUNCH, "flow_bwd_f16: image size mismatch");
-    if (rev_lds_bytes(D, S, L, U) != (2 * (int64_t)R::FLOATS + 2 * S * (int64_t)AccLayout<H, L>::INTS + (int64_t)kRevNW * 2 * kScr) * 4)
+    if (rev_lds_bytes(D, S, L, U) != (2 * (int64_t)R::FLOATS + 2 * S * (int64_t)AccLayout<H, L>::INTS + (int64_t)kRevNW * kRevNScr * kScr) * 4)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: LDS size mismatch");
     const RevWs w = rev_ws(Mp, D, S, L);
     float* rimg = reinterpret_cast<float*>(ws + w.rimg);
