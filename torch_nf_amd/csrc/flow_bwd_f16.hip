@@ -201,6 +201,22 @@ __device__ __forceinline__ T16 tsplit(f4 v, float* scr, int lane) {
     split4(transpose16(v, scr, lane), o.hi, o.lo);
     return o;
 }
+// The same re-layout on the matrix pipe, for a tile that is already split: read as an A operand the accumulator
+// layout is T^T (rows = samples, K = the tile's rows), so T^T . I comes back as [row = lane&15][samples 4q .. 4q+3].
+// Each product has one non-zero term and f16 values are exact in fp32, so the round trip is exact; it costs two
+// MFMAs and four conversions where the LDS path costs five LDS instructions and a fresh split.
+__device__ __forceinline__ h4 pack4(f4 v) {
+    const u2 w = {__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[0], v[1])),
+                  __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]))};
+    return __builtin_bit_cast(h4, w);
+}
+__device__ __forceinline__ T16 mtrans(h4 hi, h4 lo, h4 ident) {
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    T16 o;
+    o.hi = pack4(mfma16h(hi, ident, zero));
+    o.lo = pack4(mfma16h(lo, ident, zero));
+    return o;
+}
 // D[rows of a][rows of b] = sum over the 16 samples
 __device__ __forceinline__ f4 outer16h(const T16& a, const T16& b) {
     f4 acc = mfma16h(a.hi, b.hi, f4{0.f, 0.f, 0.f, 0.f});
@@ -311,9 +327,13 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
     };
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     typedef AccLayout<H, L> A_;
+    h4 ident;  // B operand of the identity: lane (n = s, q) holds K = 4q + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ident[i] = (4 * q + i == s) ? (_Float16)1.f : (_Float16)0.f;
 
     // ---- 1. forward recompute (h = tanh = 1 - 2r is what the backward needs: tanh' = 1 - h^2) ----
     f4 r[L][2], h[L][2];
+    h4 xs_hi[HT], xs_lo[HT];  // the split conditioner input, reused for its transposed form
     if constexpr (H == 32) {
         u4 a_, b_;
         split2(x[0][0], x[0][1], a_[0], b_[0]);
@@ -321,6 +341,11 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         split2(x[1][0], x[1][1], a_[2], b_[2]);
         split2(x[1][2], x[1][3], a_[3], b_[3]);
         const h8 xh = __builtin_bit_cast(h8, a_), xl = __builtin_bit_cast(h8, b_);
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            xs_hi[mm] = __builtin_bit_cast(h4, u2{a_[2 * mm], a_[2 * mm + 1]});
+            xs_lo[mm] = __builtin_bit_cast(h4, u2{b_[2 * mm], b_[2 * mm + 1]});
+        }
 #pragma unroll
         for (int net = 0; net < 2; ++net) {
             const h8 wh = __builtin_bit_cast(h8, fg[FImg::g_w0(net, 0) * 64]);
@@ -333,6 +358,8 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
     } else {
         h4 xh, xl;
         split4(x[0], xh, xl);
+        xs_hi[0] = xh;
+        xs_lo[0] = xl;
 #pragma unroll
         for (int net = 0; net < 2; ++net) {
             h4 wh, wl;
@@ -390,30 +417,29 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
         const T16 h_t = tsplit(with_ones(h[L - 1][net]), scrB, lane);
+        h4 dsh[HT], dsl[HT];
 #pragma unroll
         for (int mo = 0; mo < HT; ++mo) {
-            const T16 d_t = tsplit(dout[net][mo], scrA, lane);
+            split4(dout[net][mo], dsh[mo], dsl[mo]);
+            const T16 d_t = mtrans(dsh[mo], dsl[mo], ident);
             const f4 dw = outer16h(d_t, h_t);  // [o = 16 mo + 4q + j][k = s]
             lds_add4(acc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mo + 4 * q, dw, fa);
             if (!SPARE) lds_add_rows(acc + A_::o_b2 + net * H + 16 * mo + 4 * q, rowsum16h(d_t), s, fa);
         }
         if constexpr (H == 32) {
-            u4 a_, b_;
-            split2(dout[net][0][0], dout[net][0][1], a_[0], b_[0]);
-            split2(dout[net][0][2], dout[net][0][3], a_[1], b_[1]);
-            split2(dout[net][1][0], dout[net][1][1], a_[2], b_[2]);
-            split2(dout[net][1][2], dout[net][1][3], a_[3], b_[3]);
-            const h8 dhi = __builtin_bit_cast(h8, a_), dlo = __builtin_bit_cast(h8, b_);
+            const u2 h0_ = __builtin_bit_cast(u2, dsh[0]), h1_ = __builtin_bit_cast(u2, dsh[1]);
+            const u2 l0_ = __builtin_bit_cast(u2, dsl[0]), l1_ = __builtin_bit_cast(u2, dsl[1]);
+            const h8 dhi = __builtin_bit_cast(h8, u4{h0_[0], h0_[1], h1_[0], h1_[1]});
+            const h8 dlo = __builtin_bit_cast(h8, u4{l0_[0], l0_[1], l1_[0], l1_[1]});
             const h8 wh = __builtin_bit_cast(h8, bg[BImg::g_w2(net, 0) * 64]);
             const h8 wl = __builtin_bit_cast(h8, bg[BImg::g_w2(net, 1) * 64]);
             f4 a0 = mfma32h(wh, dhi, zero);
             a0 = mfma32h(wh, dlo, a0);
             dh[net] = mfma32h(wl, dhi, a0);
         } else {
-            h4 dhi, dlo, wh, wl;
-            split4(dout[net][0], dhi, dlo);
+            h4 wh, wl;
             hl(bg, BImg::g_w2(net, 0), wh, wl);
-            dh[net] = mm3(wh, wl, dhi, dlo, zero);
+            dh[net] = mm3(wh, wl, dsh[0], dsl[0], zero);
         }
     }
     // ---- 4. hidden layers, last to first ----
@@ -427,21 +453,22 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
                 const float hh = h[l + 1][net][j];
                 da[j] = dh[net][j] * __builtin_fmaf(-hh, hh, 1.f);
             }
-            const T16 d_t = tsplit(da, scrA, lane);
+            h4 dhi, dlo;
+            split4(da, dhi, dlo);
+            const T16 d_t = mtrans(dhi, dlo, ident);
             const T16 h_t = tsplit(with_ones(h[l][net]), scrB, lane);
             const f4 dw = outer16h(d_t, h_t);  // [k_out = 4q + j][k_in = s]
             int* ah = acc + A_::o_h + l * A_::HID;
             lds_add4(ah + (net * 16 + s) * A_::US + 4 * q, dw, fa);
             if (!SPARE) lds_add_rows(ah + 2 * 16 * A_::US + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
-            h4 dhi, dlo, wh, wl;
-            split4(da, dhi, dlo);
+            h4 wh, wl;
             hl(bg, BImg::g_wh(l, net), wh, wl);
             dh[net] = mm3(wh, wl, dhi, dlo, zero);
         }
     // ---- 5. first layer: dW0, db0, d x ----
     T16 x_t[HT];
 #pragma unroll
-    for (int mm = 0; mm < HT; ++mm) x_t[mm] = tsplit(x[mm], scrB, lane);
+    for (int mm = 0; mm < HT; ++mm) x_t[mm] = mtrans(xs_hi[mm], xs_lo[mm], ident);
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
         f4 da;
@@ -450,10 +477,10 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
             const float hh = h[0][net][j];
             da[j] = dh[net][j] * __builtin_fmaf(-hh, hh, 1.f);
         }
-        const T16 d_t = tsplit(da, scrA, lane);
-        lds_add_rows(acc + A_::o_b0 + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
         h4 dhi, dlo;
         split4(da, dhi, dlo);
+        const T16 d_t = mtrans(dhi, dlo, ident);
+        lds_add_rows(acc + A_::o_b0 + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
             const f4 dw = outer16h(d_t, x_t[mm]);  // [u = 4q + j][f = 16 mm + s]
