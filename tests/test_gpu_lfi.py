@@ -35,3 +35,71 @@ def test_train_apt_smoke():
     prior_err = np.abs(mat.simulate(mat.sample_prior(4000)) - x0).mean()
     post_err = np.abs(mat.simulate(zs[0]) - x0).mean()
     assert post_err < 0.7 * prior_err, (post_err, prior_err)
+
+
+def test_train_apt_graph_and_eager_agree_in_outcome():
+    """The same short APT run with each round's optimisation step replayed as one HIP graph (the default on a
+    HIP device) and eagerly: both must capture nothing stale -- finite, decreasing round-0 losses of the same
+    size and posteriors equally close to the observation.  (The random draws differ between the two modes, so
+    the loss sequences are compared statistically, not element-wise.)"""
+    import torch_nf_amd as tnf
+    from torch_nf_amd.lfi import train_APT
+    from torch_nf_amd.systems import Mat
+
+    out = {}
+    for mode in (True, False):
+        np.random.seed(5)
+        torch.manual_seed(5)
+        mat = Mat(2, noise=0.05)
+        x0 = np.array([[0.0, 1.0]])
+        nf = tnf.NormFlow(mat.D, True, "AR", 1, 2, 15, tnf.ToInterval(mat.D, mat.lb, mat.ub))
+        cde = tnf.ConditionalDensityEstimator(nf, 2, [32, 32])
+        msgs = []
+        import builtins
+        real_print = builtins.print
+        builtins.print = lambda *a, **k: msgs.append(" ".join(str(x) for x in a))
+        try:
+            cde, losses, zs, _, it_time = train_APT(cde, mat, x0, M=256, M_atom=16, R=1, num_iters=200, lr=2e-3,
+                                                    use_graph=mode, verbose=True)
+        finally:
+            builtins.print = real_print
+        assert not any("graph capture unavailable" in m for m in msgs), msgs  # the graphed round really replayed
+        assert losses.shape == (200,) and np.isfinite(losses).all()
+        out[mode] = (losses, np.abs(mat.simulate(zs[0]) - x0).mean(), it_time)
+    lg, le = out[True][0], out[False][0]
+    assert lg[150:].mean() < lg[:30].mean() - 0.5 and le[150:].mean() < le[:30].mean() - 0.5
+    assert abs(lg[150:].mean() - le[150:].mean()) < 0.35, (lg[150:].mean(), le[150:].mean())
+    assert abs(out[True][1] - out[False][1]) < 0.25, (out[True][1], out[False][1])
+
+
+def test_graphed_step_matches_eager_updates():
+    """graphs.GraphedStep on a deterministic step (fixed z, Adam): k replays move the parameters exactly as k eager
+    steps do, up to the order of the float atomics in the gradient reduction."""
+    import torch_nf_amd as tnf
+    from torch_nf_amd.graphs import GraphedStep
+
+    D, S, L, U, N = 32, 2, 2, 15, 4096
+    rng = np.random.RandomState(0)
+    p0 = torch.tensor(rng.normal(0, 0.1, (1, tnf.NormFlow(D, False, "coupling", S, L, U).D_params))).float()
+    z = torch.tensor(rng.normal(0, 1, (1, N, D))).float().cuda()
+    res = {}
+    for mode in ("eager", "graph"):
+        nf = tnf.NormFlow(D, False, "coupling", S, L, U)
+        nf.params = p0.clone().cuda().requires_grad_()
+        opt = torch.optim.Adam([nf.params], lr=1e-3, capturable=True)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = -nf.log_prob(z).mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        if mode == "eager":
+            ls = [step().item() for _ in range(8)]
+        else:
+            gs = GraphedStep(step, warmup=3)
+            ls = [w.item() for w in gs.warmup_outputs] + [gs().item() for _ in range(5)]
+        res[mode] = (np.array(ls), nf.params.detach().cpu())
+    np.testing.assert_allclose(res["graph"][0], res["eager"][0], rtol=1e-5)
+    torch.testing.assert_close(res["graph"][1], res["eager"][1], rtol=1e-4, atol=1e-6)

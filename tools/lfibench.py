@@ -55,6 +55,21 @@ def run(d=3, M=2000, atoms=100):
     ti, tt = timeit(infer, 10), timeit(train, 5)
     print("GPU: log_prob %.3f ms (%.1f M samples/s)   train step %.3f ms (%.1f M samples/s)"
           % (ti * 1e3, M * N / ti / 1e6, tt * 1e3, M * N / tt / 1e6))
+    # the same step with Adam, eagerly and replayed as one HIP graph (graphs.GraphedStep, what lfi.train_APT does)
+    opt = torch.optim.Adam(cde.parameters(), lr=1e-3, capturable=True)
+
+    def full_step():
+        opt.zero_grad(set_to_none=True)
+        loss = -cde.log_prob(z, x).mean()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    te = timeit(full_step, 10)
+    gs = tnf.graphs.GraphedStep(full_step, warmup=3)
+    tg = timeit(gs, 20)
+    print("GPU: step + Adam eager %.3f ms, as one HIP graph %.3f ms (%.1f M samples/s)"
+          % (te * 1e3, tg * 1e3, M * N / tg / 1e6))
     with torch.no_grad():
         cde(x[:1], N=M * N, freeze_bn=True)
     ts = timeit(lambda: cde(x[:1], N=M * N, freeze_bn=True), 5)

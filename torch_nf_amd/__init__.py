@@ -9,7 +9,7 @@ reference's import names so existing `import torch_nf.bijectors` code picks them
 import sys
 
 from . import _lib  # noqa: F401  (fails loudly if libtnf_hip.so is missing)
-from . import bijectors, conditional_density_estimator, density_estimator, error_formatters, lfi, systems
+from . import bijectors, conditional_density_estimator, density_estimator, error_formatters, graphs, lfi, systems
 from .bijectors import MAF, ToInterval, ToSimplex, Affine, BatchNorm, Bijector, RealNVP
 from .conditional_density_estimator import ConditionalDensityEstimator
 from .density_estimator import DensityEstimator, NormFlow

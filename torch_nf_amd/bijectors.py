@@ -217,16 +217,30 @@ class BatchNorm(Bijector):
     def __call__(self, z, use_last=False):
         return self.forward_and_log_det(z, use_last=use_last)
 
+    def _stats_for(self, z):
+        """The cached statistics where the kernels will read them: one copy per (version, device) instead of a
+        host-to-device transfer per call (which also cannot be captured into a HIP graph)."""
+        if not torch.cuda.is_available():
+            return self._last_mean, self._last_alpha  # ops.bn_apply raises the "needs a HIP device" error
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if self._last_mean.device == dev:
+            return self._last_mean, self._last_alpha
+        key = (self._version, dev)
+        if getattr(self, "_dev_key", None) != key:
+            self._dev_stats = (self._last_mean.detach().float().to(dev), self._last_alpha.detach().float().to(dev))
+            self._dev_key = key
+        return self._dev_stats
+
     def forward_and_log_det(self, z, use_last=False):
         if use_last:
-            return ops.bn_apply(z, self._last_mean, self._last_alpha, False)
+            return ops.bn_apply(z, *self._stats_for(z), False)
         z_norm, log_det, mean, alpha = ops.bn_batch_forward(z, self.eps)
         self._last_mean, self._last_alpha = mean, alpha
         self._version += 1
         return z_norm, log_det
 
     def inverse_and_log_det(self, z):
-        return ops.bn_apply(z, self._last_mean, self._last_alpha, True)
+        return ops.bn_apply(z, *self._stats_for(z), True)
 
 
 def _clamp_maf_layers(val):

@@ -30,7 +30,8 @@ def _atom_indices(M, M_atom, device, generator=None):
     return torch.cat((own, others), 1)
 
 
-def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3, num_sims=None, verbose=False):
+def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3, num_sims=None, verbose=False,
+              use_graph=None):
     """Train `cde` (a ConditionalDensityEstimator) towards p(z | x0) for the simulator `system`.
 
     :param system: object with sample_prior(N), log_prior(z), simulate(z) (see systems.Mat).
@@ -38,13 +39,17 @@ def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3,
     :param M: batch size (contexts per step).  :param M_atom: atoms per context.
     :param R: rounds.  :param num_iters: optimisation steps per round.
     :param num_sims: simulations per round (default 10 * M).
+    :param use_graph: replay each round's optimisation step as one HIP graph (graphs.GraphedStep); default: on a
+        HIP device.  A round whose step cannot be captured runs eagerly.
     :return: (cde, losses (R * num_iters), zs [R x (n, D)] posterior samples after each round,
               log_probs [R x (n,)], it_time seconds per iteration) -- the five values of the reference's call site.
     """
     dev = next(cde.param_net.parameters()).device
+    if use_graph is None:
+        use_graph = dev.type == "cuda"
     num_sims = num_sims or 10 * M
     x0_t = torch.as_tensor(np.asarray(x0), dtype=torch.float32, device=dev).reshape(1, -1)
-    opt = torch.optim.Adam(cde.param_net.parameters(), lr=lr)
+    opt = torch.optim.Adam(cde.param_net.parameters(), lr=lr, capturable=bool(use_graph))
     Z = torch.empty((0, system.D), dtype=torch.float32, device=dev)
     X = torch.empty((0, x0_t.shape[1]), dtype=torch.float32, device=dev)
     losses, zs, log_probs = [], [], []
@@ -62,11 +67,11 @@ def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3,
         X = torch.cat((X, torch.as_tensor(x_new[ok], dtype=torch.float32, device=dev)))
         n = Z.shape[0]
         Mb = min(M, n)
-        torch.cuda.synchronize() if dev.type == "cuda" else None
-        t0 = time.perf_counter()
-        for _ in range(num_iters):
+        Z_r, X_r = Z, X  # this round's pairs: fixed addresses for the captured step
+
+        def step():
             idx = torch.randint(0, n, (Mb,), device=dev)
-            z_b, x_b = Z[idx], X[idx]
+            z_b, x_b = Z_r[idx], X_r[idx]
             atoms = _atom_indices(Mb, M_atom, dev)
             z_atoms = z_b[atoms]                                  # (Mb, M_atom, D)
             lp = cde.log_prob(z_atoms, x_b) - system.log_prior(z_atoms)
@@ -74,7 +79,27 @@ def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3,
             opt.zero_grad(set_to_none=True)
             loss.backward()
             opt.step()
-            losses.append(loss.detach())
+            return loss.detach()
+
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+        t0 = time.perf_counter()
+        done = 0
+        if use_graph and num_iters > 4:
+            try:
+                from .graphs import GraphedStep
+
+                gs = GraphedStep(step, warmup=3)
+                losses.extend(gs.warmup_outputs)
+                done = 3
+                for _ in range(num_iters - done):
+                    losses.append(gs().clone())
+                done = num_iters
+            except RuntimeError as e:  # a step this device / build cannot capture: finish the round eagerly
+                if verbose:
+                    print("round %d: graph capture unavailable (%s), running eagerly" % (r, str(e).splitlines()[0]))
+                torch.cuda.synchronize()
+        for _ in range(num_iters - done):
+            losses.append(step())
         torch.cuda.synchronize() if dev.type == "cuda" else None
         t_train += time.perf_counter() - t0
         n_it += num_iters

@@ -32,8 +32,12 @@ class Mat(object):
         """log density of the uniform prior, -inf outside the box; z (..., D) numpy or torch."""
         vol = float(np.sum(np.log(self.ub - self.lb)))
         if torch.is_tensor(z):
-            lb = torch.as_tensor(self.lb, dtype=z.dtype, device=z.device)
-            ub = torch.as_tensor(self.ub, dtype=z.dtype, device=z.device)
+            key = (z.dtype, z.device)  # device copies of the bounds are made once (and keep the step capturable)
+            if getattr(self, "_bounds_key", None) != key:
+                self._bounds = (torch.as_tensor(self.lb, dtype=z.dtype, device=z.device),
+                                torch.as_tensor(self.ub, dtype=z.dtype, device=z.device))
+                self._bounds_key = key
+            lb, ub = self._bounds
             inside = ((z >= lb) & (z <= ub)).all(-1)
             return torch.where(inside, torch.full(inside.shape, -vol, dtype=z.dtype, device=z.device),
                                torch.full(inside.shape, -float("inf"), dtype=z.dtype, device=z.device))
