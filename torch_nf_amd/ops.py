@@ -419,7 +419,9 @@ class _FlowLogProbFn(torch.autograd.Function):
 
 def flow_train_rev_supported(M, Mp, N, D, S, L, U):
     """The reversible pair: whole-flow forward that keeps only z0, one-kernel backward."""
-    return Mp in (1, M) and N >= 1 and lib.tnf_flow_train_rev_supported(D, S, L, U) == 1
+    # per-context parameter rows with a handful of samples each (the SNPE layout) are not this kernel's case:
+    # every context would build ~170 KB of operand images for one tile (conditional_density_estimator fuses those)
+    return Mp in (1, M) and N >= 1 and (Mp == 1 or N >= 32) and lib.tnf_flow_train_rev_supported(D, S, L, U) == 1
 
 
 class _FlowLogProbRevFn(torch.autograd.Function):
