@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline path only: skip the training step and the widened rows (keeps a rocprofv3 "
+                         "--stats average of the headline kernel free of their smaller launches)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), 16)")
     args = ap.parse_args()
 
@@ -232,7 +235,7 @@ def main():
     # BASELINE configs[3], per-GPU share: one training step (loss = -mean log_prob, backward, Adam)
     # on 2^19 samples; outside the timed region.  With N GPUs the only collective is the gradient.
     train_ms = None
-    if rank == 0 or world > 1:
+    if (rank == 0 or world > 1) and not args.no_extras:
         n_tr = 1 << 19
         p_train = nf.params.detach().clone().requires_grad_()
         nf_params_saved, nf.params = nf.params, p_train
@@ -333,11 +336,11 @@ def main():
         "train_step": None if train_ms is None else {
             "ms": round(train_ms, 3), "samples_per_gpu": 1 << 19,
             "value": round((1 << 19) * world / (train_ms * 1e-3) / 1e6, 1), "unit": "M samples/s",
-            "what": "loss = -mean(log_prob); backward (MFMA backward kernels); "
+            "what": "loss = -mean(log_prob): whole-flow forward keeping z0, one-kernel reversible backward (split-f16 MFMA); "
                     + ("RCCL all-reduce of the flat gradient; " if world > 1 else "") + "Adam step"},
     }
 
-    if world == 1:
+    if world == 1 and not args.no_extras:
         out["widened"] = widened_rows(tnf)
 
     if not args.no_cpu_baseline and world == 1:

@@ -234,7 +234,7 @@ __device__ __forceinline__ f4 mm3(h4 wh, h4 wl, h4 xh, h4 xl, f4 acc) {
     return mfma16h(wl, xh, acc);
 }
 // LDS accumulators are 32-bit FIXED POINT (value * fx): on gfx950 ds_add_f32 costs ~190 cycles per
-// wave-instruction, ds_add_u32 ~4 (scratch/lds_atomic_bench.hip), and a wave's 16-sample tile needs ~60 of them
+// wave-instruction, ds_add_u32 ~4 (tools/lds_atomic_bench.hip), and a wave's 16-sample tile needs ~60 of them
 // per layer.  fx is chosen on the host so that 2^13 per accumulated term cannot overflow (see launch_rev);
 // amax tracks the largest term so the kernel can tell when that budget did not hold.
 //
