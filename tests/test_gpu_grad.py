@@ -221,3 +221,31 @@ def test_flow_reversible_backward_scales_and_no_gz(tnf, oracle, D, U, N, scale):
     assert nf._train_path(z, p) == "reversible"
     (-nf.log_prob(z, p).mean() * scale).backward()
     torch.testing.assert_close(p.grad.cpu() / scale, p_ref.grad / scale, rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("N", [1, 17])
+def test_flow_reversible_backward_tiny_batches(tnf, oracle, N):
+    """One partial tile: rows beyond N are clamped loads with zero upstream gradient."""
+    D, S, L, U = 64, 4, 2, 15
+    rng = np.random.RandomState(N)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.1, (1, nf.D_params))).float()
+    z0 = torch.tensor(rng.normal(0, 1, (1, N, D))).float()
+    p_ref, z_ref = p0.clone().requires_grad_(), z0.clone().requires_grad_()
+    stats = [(torch.zeros(D), torch.ones(D))] * (2 * S)  # the BatchNorm layers' initial cached statistics
+    oracle.flow_log_prob(z_ref, p_ref, D, S, L, U, stats).sum().backward()
+    p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
+    assert nf._train_path(z, p) == "reversible"
+    nf.log_prob(z, p).sum().backward()
+    torch.testing.assert_close(z.grad.cpu(), z_ref.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(p.grad.cpu(), p_ref.grad, rtol=5e-4, atol=5e-4 * float(p_ref.grad.abs().max()))
+
+
+def test_flow_reversible_backward_zero_upstream(tnf):
+    """All-zero upstream gradient (max |g| = 0: no rescaling possible) gives exactly zero gradients."""
+    D, S, L, U, N = 32, 2, 2, 15, 100
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p = (torch.randn(1, nf.D_params) * 0.1).cuda().requires_grad_()
+    z = torch.randn(1, N, D).cuda().requires_grad_()
+    (nf.log_prob(z, p) * 0.0).sum().backward()
+    assert float(p.grad.abs().max()) == 0.0 and float(z.grad.abs().max()) == 0.0
