@@ -114,7 +114,7 @@ struct MafBwdArgs {
     float* g_z;
     float* g_params;
     int64_t M, Mp, N, pstride, gpstride;
-    int D, L, U;
+    int D, L, U, nacc;
 };
 
 constexpr int kMafLMax = 3;
@@ -127,8 +127,12 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     const int NWG = wl.NWG();
     float* fimg = lds;
     float* timg = fimg + wl.fwd_floats();
+    // weight-gradient accumulators: nacc = 4 -> one private copy per wave, plain read-add-write (ds_add_f32 costs
+    // ~190 cycles per wave-instruction on gfx950, tools/lds_atomic_bench.hip); nacc = 1 (the copies do not fit the
+    // LDS) -> one shared copy and float atomics
+    const int nacc = a.nacc;
     float* gacc = timg + NWG * 256;
-    float* scr_all = gacc + NWG * 256;
+    float* scr_all = gacc + nacc * NWG * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     float* scrA = scr_all + wave * 2 * 272;
@@ -136,21 +140,26 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     const int64_t m = grid_m();
     if (m >= a.M) return;
     const int64_t mp = a.Mp == 1 ? 0 : m;
-    for (int i = threadIdx.x; i < NWG * 256; i += 256) gacc[i] = 0.f;
+    for (int i = threadIdx.x; i < nacc * NWG * 256; i += 256) gacc[i] = 0.f;
     build_maf_bwd_images(fimg, timg, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4);
     __syncthreads();
 
     const float* fsrc = fimg + lane * 4;
     const float* bsrc = fimg + NWG * 256 + q * 4;
     const float* tsrc = timg + lane * 4;
-    float* gdst = gacc + lane * 4;
+    float* gdst = gacc + (nacc > 1 ? wave * NWG * 256 : 0) + lane * 4;
     auto wgrp = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(fsrc + g * 256); };
     auto bgrp = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(bsrc + g * 16); };
     auto tgrp = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(tsrc + g * 256); };
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     auto gadd = [&](int g, f4 v) {
+        if (nacc > 1) {
+            f4* p = reinterpret_cast<f4*>(gdst + g * 256);
+            *p = *p + v;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(gdst + g * 256 + j, v[j]);  // ds_add_f32
+            for (int j = 0; j < 4; ++j) atomicAdd(gdst + g * 256 + j, v[j]);  // ds_add_f32
+        }
     };
 
     const float* zb = a.z + m * a.N * D;
@@ -366,7 +375,8 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
             for (int t = wave; t < 2 * OT * IT; t += 4) {
                 const int net = t / (OT * IT), rem = t - net * OT * IT, ot = rem / IT, it = rem - ot * IT;
                 const int gidx = layer == 0 ? wl.g0(net, ot, it) : (layer == L ? wl.g2(net, ot, it) : wl.gh(layer - 1, net, ot, it));
-                const f4 v = *reinterpret_cast<const f4*>(gacc + (gidx * 64 + lane) * 4);
+                f4 v = *reinterpret_cast<const f4*>(gacc + (gidx * 64 + lane) * 4);
+                for (int c = 1; c < nacc; ++c) v += *reinterpret_cast<const f4*>(gacc + c * NWG * 256 + (gidx * 64 + lane) * 4);
                 const int k = 16 * it + s;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -394,8 +404,8 @@ static MafBLayout maf_blayout(int D, int L, int U) {
     return wl;
 }
 
-static size_t maf_bwd_smem(const MafBLayout& wl) {
-    return (size_t)(wl.fwd_floats() + 2 * wl.NWG() * 256 + 4 * 2 * 272) * sizeof(float);
+static size_t maf_bwd_smem(const MafBLayout& wl, int nacc = 1) {
+    return (size_t)(wl.fwd_floats() + (1 + nacc) * wl.NWG() * 256 + 4 * 2 * 272) * sizeof(float);
 }
 
 bool maf_bwd_mfma_supported(int D, int L, int U) {
@@ -437,8 +447,10 @@ int launch_maf_backward_mfma(const float* z, const float* params, const float* m
         return fail(TNF_EUNSUPPORTED, "maf_bwd_mfma: no kernel for D=%d L=%d U=%d", D, L, U);
     if (N <= 0) return TNF_OK;
     const MafBLayout wl = maf_blayout(D, L, U);
-    const size_t smem = maf_bwd_smem(wl);
+    const int nacc = maf_bwd_smem(wl, 4) <= 156 * 1024 ? 4 : 1;
+    const size_t smem = maf_bwd_smem(wl, nacc);
     MafBwdArgs a;
+    a.nacc = nacc;
     a.z = z; a.params = params; a.masks = masks; a.g_zout = g_zout; a.g_ld = g_ld; a.g_z = g_z; a.g_params = g_params;
     a.M = M; a.Mp = Mp; a.N = N; a.pstride = pstride; a.gpstride = gpstride; a.D = D; a.L = L; a.U = U;
     const int64_t ntiles = (N + 15) / 16;
