@@ -275,6 +275,21 @@ int tnf_ar_flow_forward_f32(const float* omega, const float* params, const float
                             int64_t N, int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Training through NormFlow(arch_type="AR").log_prob (density_estimator.py:390-416 under autograd, the inner
+ * loop of scripts/lfi_mat.py:23-57): gradient of sum(g_log_prob * log_prob) w.r.t. the parameter rows
+ * [MAF | Affine alpha | Affine shift] in ONE backward kernel -- it applies ToInterval^-1 (interval_consts,
+ * may be NULL) and the folded Affine^-1 . BatchNorm^-1 itself, recomputes the MAF, seeds the backward from
+ * g_log_prob (base density and log-dets) and reduces the MAF and Affine gradients.  z (M,N,D) is a constant of
+ * the graph (no g_z); the forward is tnf_ar_flow_log_prob_f32.  g_params: M_p rows, accumulated, zero it first.
+ * BatchNorm statistics are constants.  Shapes: tnf_ar_flow_train_supported() (D <= 32, num_layers <= 3). */
+int tnf_ar_flow_train_supported(int32_t D, int32_t num_layers, int32_t num_units);
+int64_t tnf_ar_flow_bwd_workspace_bytes(int64_t M_p, int32_t D);
+int tnf_ar_flow_log_prob_bwd_f32(const float* z, const float* params, const float* masks, const float* bn_mean,
+                                 const float* bn_alpha, const float* interval_consts, const float* g_log_prob,
+                                 float* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t num_layers,
+                                 int32_t num_units, int64_t params_row_stride, int64_t g_params_row_stride,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Base density of NormFlow.forward, float64 like the reference's numpy expression
  * log(prod_d exp(-w_d^2/2)/sqrt(2 pi)) (density_estimator.py:369-372), evaluated as
  * sum_d(-w_d^2/2) - D*log(sqrt(2 pi)) in float64.  omega (rows, D) of `dtype` (TNF_F64 for

@@ -223,3 +223,48 @@ def test_maf_backward_mfma(tnf, oracle, D, L, U, Mz, Mp, N):
         idx += [off + i for i in range(2 * n) if Mk.reshape(-1)[i % n] == 0]
         off += 2 * n
     assert float(grads[0][1][:, idx].abs().max()) == 0.0 if idx else True
+
+
+@pytest.mark.parametrize("D,L,U,M,Mp,N,support", [(6, 2, 15, 40, 40, 100, True), (6, 2, 15, 3, 1, 257, True),
+                                                   (21, 2, 42, 8, 8, 50, True), (16, 3, 32, 2, 2, 64, False),
+                                                   (5, 1, 20, 1, 1, 33, False)])
+def test_ar_flow_training_one_kernel_backward(tnf, oracle, D, L, U, M, Mp, N, support):
+    """NormFlow('AR').log_prob with z constant and params requiring grad: forward = the one-kernel inference path,
+    backward = tnf_ar_flow_log_prob_bwd_f32 (ToInterval^-1, folded Affine / BatchNorm, MAF recompute + backward,
+    base density in one kernel).  Gradients w.r.t. the parameter rows against (a) this package's per-bijector
+    autograd path and (b) torch autograd over the oracle (= the reference's training path)."""
+    rng = np.random.RandomState(D + M + N)
+    torch.manual_seed(D + M)
+    lb, ub = -2.0 * np.ones(D), 2.0 * np.ones(D)
+    lb[::2] = -np.inf
+    sup = tnf.ToInterval(D, lb, ub) if support else None
+    nf = tnf.NormFlow(D, True, "AR", 1, L, U, sup)
+    nf.bijectors[1].set_last_stats(torch.tensor(rng.normal(0, 0.3, D)).float(),
+                                   torch.tensor(np.exp(rng.normal(0, 0.2, D))).float())
+    p0 = torch.tensor(rng.normal(0, 0.2, (Mp, nf.D_params))).float()
+    z = torch.tensor(rng.uniform(-1.5, 1.5, (M, N, D))).float().cuda()
+    w = torch.tensor(rng.uniform(0.2, 1.0, (M, N))).float().cuda()
+    res = {}
+    for fused in (True, False):
+        nf.fused_ar_training = fused
+        p = p0.clone().cuda().requires_grad_()
+        assert nf._ar_train_ok(z, p) == fused
+        loss = -(nf.log_prob(z, p) * w).sum() / N
+        loss.backward()
+        res[fused] = (loss.detach().cpu(), p.grad.cpu())
+    # (b) oracle
+    Ms = [Mk[0].numpy() for Mk in nf.bijectors[0].Ms]
+    stat = (nf.bijectors[1].get_last_mean().cpu().float(), nf.bijectors[1].get_last_alpha().cpu().float())
+    pr = p0.clone().requires_grad_()
+    zc = z.cpu()
+    if support:
+        zi, ld = oracle.to_interval(zc, oracle.interval_consts(lb, ub), True)
+    else:
+        zi, ld = zc, 0.0
+    lp = oracle.ar_flow_log_prob(zi, pr, D, nf.num_layers, nf.num_units, Ms, stat) - ld
+    loss_o = -(lp * w.cpu()).sum() / N
+    loss_o.backward()
+    scale = float(pr.grad.abs().max())
+    torch.testing.assert_close(res[True][0], loss_o.detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=2e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(res[True][1], pr.grad, rtol=5e-4, atol=5e-5 * scale)

@@ -341,6 +341,44 @@ int tnf_ar_flow_forward_f32(const float* omega, const float* params, const float
                        M_z, M_p, N, D, L, U, pstride, workspace, workspace_bytes, stream);
 }
 
+// ---- training through NormFlow('AR').log_prob: parameter gradients of the whole stack in one backward kernel ----
+int tnf_ar_flow_train_supported(int32_t D, int32_t L, int32_t U) {
+    return (maf_mfma_supported(D, L, U) && maf_bwd_mfma_supported(D, L, U)) ? 1 : 0;
+}
+
+int64_t tnf_ar_flow_bwd_workspace_bytes(int64_t M_p, int32_t D) {
+    if (M_p < 1 || D < 1) return fail(TNF_EINVAL, "tnf_ar_flow_bwd_workspace_bytes: M_p=%lld D=%d", (long long)M_p, D);
+    return round16(M_p * (4 * (int64_t)D + 2) * (int64_t)sizeof(float));
+}
+
+int tnf_ar_flow_log_prob_bwd_f32(const float* z, const float* params, const float* masks, const float* bn_mean,
+                                 const float* bn_alpha, const float* interval_consts, const float* g_log_prob,
+                                 float* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U,
+                                 int64_t pstride, int64_t gpstride, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    const char* fn = "tnf_ar_flow_log_prob_bwd_f32";
+    if (M < 1 || N < 0 || (M_p != 1 && M_p != M))
+        return fail(TNF_EINVAL, "%s: M=%lld M_p=%lld N=%lld", fn, (long long)M, (long long)M_p, (long long)N);
+    if (!tnf_ar_flow_train_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "%s: no kernel for D=%d L=%d U=%d", fn, D, L, U);
+    const int64_t p_maf = tnf_maf_num_params(D, L, U);
+    if (pstride < p_maf + 2 * (int64_t)D || gpstride < p_maf + 2 * (int64_t)D)
+        return fail(TNF_EINVAL, "%s: parameter rows shorter than %lld", fn, (long long)(p_maf + 2 * D));
+    if (!z || !params || !masks || !bn_mean || !bn_alpha || !g_log_prob || !g_params || !workspace)
+        return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    if (workspace_bytes < tnf_ar_flow_bwd_workspace_bytes(M_p, D))
+        return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)workspace_bytes,
+                    (long long)tnf_ar_flow_bwd_workspace_bytes(M_p, D));
+    if (N == 0) return TNF_OK;
+    float* fold = (float*)workspace;
+    float* ldc = fold + M_p * 2 * (int64_t)D;
+    float* g_fold = ldc + M_p;
+    float* glp_sum = g_fold + M_p * 2 * (int64_t)D;
+    int rc = launch_ar_fold(params, pstride, p_maf, bn_mean, bn_alpha, fold, ldc, M_p, D, 1, as_stream(stream));
+    if (rc) return rc;
+    return launch_ar_flow_backward(z, params, masks, fold, interval_consts, g_log_prob, g_params, g_fold, glp_sum, M, M_p,
+                                   N, D, L, U, pstride, gpstride, as_stream(stream));
+}
+
 int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
                      const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D,
                      int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* stream) {

@@ -15,6 +15,7 @@
 // LDS once, masked, by plain stores (per-context rows, one workgroup per row) or one atomic per
 // parameter per workgroup.
 #include "mfma_tile.h"
+#include "support_math.h"
 #include "tnf_common.h"
 
 namespace tnf {
@@ -115,6 +116,16 @@ struct MafBwdArgs {
     float* g_params;
     int64_t M, Mp, N, pstride, gpstride;
     int D, L, U, nacc;
+    // fused NormFlow('AR').log_prob training (tnf_ar_flow_log_prob_bwd_f32): z is the flow's input; the kernel
+    // applies ToInterval^-1 (iv, may be NULL) and the folded Affine^-1 . BatchNorm^-1 (pre: A | B per context)
+    // itself, seeds the backward from g_lp (g_out = -g_lp out, g_ld = -g_lp), and reduces the fold gradients
+    // dA = sum g x_pre, dB = sum g (g_fold: (Mp, 2, D)) and sum g_lp (glp_sum: (Mp)); g_zout / g_ld are unused
+    // and g_z may be NULL.
+    const float* pre;
+    const float* iv;
+    const float* g_lp;
+    float* g_fold;
+    float* glp_sum;
 };
 
 constexpr int kMafLMax = 3;
@@ -133,6 +144,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     const int nacc = a.nacc;
     float* gacc = timg + NWG * 256;
     float* scr_all = gacc + nacc * NWG * 256;
+    float* cst = scr_all + 4 * 2 * 272;  // fused mode: fold A | B (2 D), ToInterval constants (7 D), reduction slots (2 D + 1)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
     float* scrA = scr_all + wave * 2 * 272;
@@ -141,6 +153,14 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     if (m >= a.M) return;
     const int64_t mp = a.Mp == 1 ? 0 : m;
     for (int i = threadIdx.x; i < nacc * NWG * 256; i += 256) gacc[i] = 0.f;
+    const bool fusedm = a.g_lp != nullptr;
+    const bool has_iv = a.iv != nullptr;
+    if (fusedm) {
+        for (int i = threadIdx.x; i < 2 * D; i += 256) cst[i] = a.pre[mp * 2 * D + i];
+        if (has_iv)
+            for (int i = threadIdx.x; i < 7 * D; i += 256) cst[2 * D + i] = a.iv[i];
+        for (int i = threadIdx.x; i < 2 * D + 1; i += 256) cst[9 * D + i] = 0.f;
+    }
     build_maf_bwd_images(fimg, timg, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4);
     __syncthreads();
 
@@ -163,31 +183,55 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     };
 
     const float* zb = a.z + m * a.N * D;
-    const float* gob = a.g_zout + m * a.N * D;
-    const float* glb = a.g_ld + m * a.N;
-    float* gzb = a.g_z + m * a.N * D;
+    const float* gob = fusedm ? nullptr : a.g_zout + m * a.N * D;
+    const float* glb = (fusedm ? a.g_lp : a.g_ld) + m * a.N;
+    float* gzb = a.g_z ? a.g_z + m * a.N * D : nullptr;
+    f4 fdA[DT], fdB[DT];  // fused mode: this lane's share of dA, dB
+#pragma unroll
+    for (int mm = 0; mm < DT; ++mm) fdA[mm] = fdB[mm] = zero;
+    float glp_acc = 0.f;
 
     const int64_t ntiles = (a.N + 15) >> 4;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t row = tile * 16 + s;
         const bool row_ok = row < a.N;
         const int64_t rr = row_ok ? row : a.N - 1;
-        f4 x[DT], g[DT];
+        f4 x[DT], g[DT], xpre[DT];
 #pragma unroll
         for (int mm = 0; mm < DT; ++mm) {
             const int f0 = 16 * mm + 4 * q;
             if (VEC) {
                 x[mm] = f0 < D ? *reinterpret_cast<const f4*>(zb + rr * D + f0) : zero;
-                g[mm] = (f0 < D && row_ok) ? *reinterpret_cast<const f4*>(gob + rr * D + f0) : zero;
+                g[mm] = (!fusedm && f0 < D && row_ok) ? *reinterpret_cast<const f4*>(gob + rr * D + f0) : zero;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     x[mm][j] = ld_sel(zb + rr * D, f0 + j, f0 + j < D);
-                    g[mm][j] = row_ok ? ld_sel(gob + rr * D, f0 + j, f0 + j < D) : 0.f;
+                    g[mm][j] = (!fusedm && row_ok) ? ld_sel(gob + rr * D, f0 + j, f0 + j < D) : 0.f;
+                }
+            }
+            xpre[mm] = zero;
+            if (fusedm) {  // the bijectors in front of the MAF: ToInterval^-1, then x A + B
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = f0 + j;
+                    float v = x[mm][j];
+                    if (f < D) {
+                        if (has_iv) {
+                            float o, l;
+                            interval_fast<true>(v, cst + 2 * D, D, f, o, l);
+                            v = o;
+                        }
+                        xpre[mm][j] = v;
+                        v = __builtin_fmaf(v, cst[f], cst[D + f]);
+                    }
+                    x[mm][j] = v;
                 }
             }
         }
-        const float gl = row_ok ? glb[rr] : 0.f;
+        const float glv = row_ok ? glb[rr] : 0.f;
+        const float gl = fusedm ? -glv : glv;  // log_prob = base - (sum of forward log-dets)
+        if (fusedm && q == 0) glp_acc += glv;
         asm volatile("" ::: "memory");
 
         // ---- 1. forward recompute, keeping r of every hidden level ----
@@ -250,7 +294,8 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float e = __builtin_amdgcn_exp2f(-al2[j]);
-                const float ge = g[mo][j] * e;
+                const float gup = fusedm ? -glv * ((x[mo][j] - mu[j]) * e) : g[mo][j];  // d(-|out|^2/2)/d out . g_lp
+                const float ge = gup * e;
                 gz[j] = ge;
                 dlt[0][mo][j] = -ge;
                 // padded features (f >= D): x = mu = 0 and g = 0, but g_ld must not leak into them
@@ -347,7 +392,18 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                 g[mm] += acc;
             }
         }
-        if (row_ok) {
+        if (fusedm) {
+#pragma unroll
+            for (int mm = 0; mm < DT; ++mm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fdA[mm][j] = __builtin_fmaf(g[mm][j], xpre[mm][j], fdA[mm][j]);
+                    fdB[mm][j] += g[mm][j];
+                    const int f = 16 * mm + 4 * q + j;
+                    if (gzb && f < D) g[mm][j] *= cst[f];  // g wrt the MAF input -> wrt the fold's input (no ToInterval here)
+                }
+        }
+        if (row_ok && gzb) {
 #pragma unroll
             for (int mm = 0; mm < DT; ++mm) {
                 const int f0 = 16 * mm + 4 * q;
@@ -359,6 +415,37 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                         if (f0 + j < D) gzb[row * D + f0 + j] = g[mm][j];
                 }
             }
+        }
+    }
+
+    if (fusedm) {  // fold gradients: 16 sample lanes -> LDS (once per wave) -> global
+        float* red = cst + 9 * D;
+#pragma unroll
+        for (int mm = 0; mm < DT; ++mm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float va = fdA[mm][j], vb = fdB[mm][j];
+                for (int off = 8; off > 0; off >>= 1) {
+                    va += __shfl_xor(va, off);
+                    vb += __shfl_xor(vb, off);
+                }
+                const int f = 16 * mm + 4 * q + j;
+                if (s == 0 && f < D) {
+                    atomicAdd(red + f, va);
+                    atomicAdd(red + D + f, vb);
+                }
+            }
+        for (int off = 8; off > 0; off >>= 1) glp_acc += __shfl_xor(glp_acc, off);
+        if (lane == 0) atomicAdd(red + 2 * D, glp_acc);
+        __syncthreads();
+        const bool own_row = a.Mp > 1 && gridDim.x == 1;
+        for (int i = threadIdx.x; i < 2 * D; i += 256) {
+            if (own_row) a.g_fold[mp * 2 * D + i] = red[i];
+            else atomicAdd(a.g_fold + mp * 2 * D + i, red[i]);
+        }
+        if (threadIdx.x == 0) {
+            if (own_row) a.glp_sum[mp] = red[2 * D];
+            else atomicAdd(a.glp_sum + mp, red[2 * D]);
         }
     }
     __syncthreads();
@@ -405,7 +492,7 @@ static MafBLayout maf_blayout(int D, int L, int U) {
 }
 
 static size_t maf_bwd_smem(const MafBLayout& wl, int nacc = 1) {
-    return (size_t)(wl.fwd_floats() + (1 + nacc) * wl.NWG() * 256 + 4 * 2 * 272) * sizeof(float);
+    return (size_t)(wl.fwd_floats() + (1 + nacc) * wl.NWG() * 256 + 4 * 2 * 272 + 11 * 16 * wl.DT + 4) * sizeof(float);
 }
 
 bool maf_bwd_mfma_supported(int D, int L, int U) {
@@ -440,27 +527,77 @@ static int launch_maf_bwd_d(const MafBwdArgs& a, const MafBLayout& wl, dim3 grid
     }
 }
 
+static int launch_maf_bwd_args(MafBwdArgs& a, hipStream_t st) {
+    const MafBLayout wl = maf_blayout(a.D, a.L, a.U);
+    const int nacc = maf_bwd_smem(wl, 4) <= 156 * 1024 ? 4 : 1;
+    const size_t smem = maf_bwd_smem(wl, nacc);
+    a.nacc = nacc;
+    const int64_t ntiles = (a.N + 15) / 16;
+    int64_t bx = (ntiles + 3) / 4;
+    if (a.Mp > 1) bx = 1;  // one workgroup owns the context's gradient row: plain stores
+    else if (bx > 512) bx = 512;
+    const dim3 grid = grid_xm(bx, a.M);
+    int rc = wl.DT == 1 ? launch_maf_bwd_d<1>(a, wl, grid, smem, st) : launch_maf_bwd_d<2>(a, wl, grid, smem, st);
+    if (rc != TNF_OK) return rc;
+    return check_launch("maf_bwd_mfma");
+}
+
 int launch_maf_backward_mfma(const float* z, const float* params, const float* masks, const float* g_zout,
                              const float* g_ld, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int D,
                              int L, int U, int64_t pstride, int64_t gpstride, hipStream_t st) {
     if (!maf_bwd_mfma_supported(D, L, U))
         return fail(TNF_EUNSUPPORTED, "maf_bwd_mfma: no kernel for D=%d L=%d U=%d", D, L, U);
     if (N <= 0) return TNF_OK;
-    const MafBLayout wl = maf_blayout(D, L, U);
-    const int nacc = maf_bwd_smem(wl, 4) <= 156 * 1024 ? 4 : 1;
-    const size_t smem = maf_bwd_smem(wl, nacc);
-    MafBwdArgs a;
-    a.nacc = nacc;
+    MafBwdArgs a = {};
     a.z = z; a.params = params; a.masks = masks; a.g_zout = g_zout; a.g_ld = g_ld; a.g_z = g_z; a.g_params = g_params;
     a.M = M; a.Mp = Mp; a.N = N; a.pstride = pstride; a.gpstride = gpstride; a.D = D; a.L = L; a.U = U;
-    const int64_t ntiles = (N + 15) / 16;
-    int64_t bx = (ntiles + 3) / 4;
-    if (Mp > 1) bx = 1;  // one workgroup owns the context's gradient row: plain stores
-    else if (bx > 512) bx = 512;
-    const dim3 grid = grid_xm(bx, M);
-    int rc = wl.DT == 1 ? launch_maf_bwd_d<1>(a, wl, grid, smem, st) : launch_maf_bwd_d<2>(a, wl, grid, smem, st);
+    return launch_maf_bwd_args(a, st);
+}
+
+// [ToInterval^-1,] Affine^-1, BatchNorm^-1, MAF^-1, base density: gradient of log_prob w.r.t. the parameter rows.
+//   fold (Mp, 2, D): A | B of launch_ar_fold(inverse);  g_fold (Mp, 2, D) + glp_sum (Mp): zeroed by the caller.
+__global__ void __launch_bounds__(64)
+ar_fold_backward_kernel(const float* __restrict__ params, int64_t pstride, int64_t p_maf, const float* __restrict__ fold,
+                        const float* __restrict__ g_fold, const float* __restrict__ glp_sum, float* __restrict__ g_params,
+                        int64_t gpstride, int D, int accumulate) {
+    const int64_t m = blockIdx.x;
+    const float* ap = params + m * pstride + p_maf;
+    float* gp = g_params + m * gpstride + p_maf;
+    const float sg = glp_sum[m];
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const float A = fold[m * 2 * D + d], sh = ap[D + d];
+        const float dA = g_fold[m * 2 * D + d], dB = g_fold[m * 2 * D + D + d];
+        // A = alpha_bn e^-a, B = mean_bn - shift A;  log_prob also carries -sum a
+        const float ga = -A * dA + sh * A * dB - sg, gs = -A * dB;
+        if (accumulate) {
+            atomicAdd(gp + d, ga);
+            atomicAdd(gp + D + d, gs);
+        } else {
+            gp[d] = ga;
+            gp[D + d] = gs;
+        }
+    }
+}
+
+int launch_ar_flow_backward(const float* z, const float* params, const float* masks, const float* fold,
+                            const float* interval_consts, const float* g_lp, float* g_params, float* g_fold,
+                            float* glp_sum, int64_t M, int64_t Mp, int64_t N, int D, int L, int U, int64_t pstride,
+                            int64_t gpstride, hipStream_t st) {
+    if (!maf_bwd_mfma_supported(D, L, U))
+        return fail(TNF_EUNSUPPORTED, "ar_flow_backward: no kernel for D=%d L=%d U=%d", D, L, U);
+    if (N <= 0) return TNF_OK;
+    if (hipMemsetAsync(g_fold, 0, (size_t)(Mp * 2 * D + Mp) * sizeof(float), st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "ar_flow_backward: memset failed");
+    MafBwdArgs a = {};
+    a.z = z; a.params = params; a.masks = masks; a.g_params = g_params;
+    a.M = M; a.Mp = Mp; a.N = N; a.pstride = pstride; a.gpstride = gpstride; a.D = D; a.L = L; a.U = U;
+    a.pre = fold; a.iv = interval_consts; a.g_lp = g_lp; a.g_fold = g_fold; a.glp_sum = glp_sum;
+    int rc = launch_maf_bwd_args(a, st);
     if (rc != TNF_OK) return rc;
-    return check_launch("maf_bwd_mfma");
+    const int64_t p_maf = 2 * ((int64_t)D * U + (int64_t)(L - 1) * U * U + (int64_t)U * D) + 0;
+    hipLaunchKernelGGL(ar_fold_backward_kernel, dim3((unsigned)Mp), dim3(64), 0, st, params, pstride, p_maf, fold, g_fold,
+                       glp_sum, g_params, gpstride, D, 1);
+    return check_launch("ar_fold_backward");
 }
 
 }  // namespace tnf

@@ -228,6 +228,10 @@ int launch_maf_mfma(const MafArgs& a, hipStream_t st);
 int launch_ar_fold(const float* params, int64_t pstride, int64_t p_maf, const float* bn_mean, const float* bn_alpha,
                    float* fold, float* ldc, int64_t Mp, int D, int inverse, hipStream_t st);
 bool maf_bwd_mfma_supported(int D, int L, int U);
+int launch_ar_flow_backward(const float* z, const float* params, const float* masks, const float* fold,
+                            const float* interval_consts, const float* g_lp, float* g_params, float* g_fold,
+                            float* glp_sum, int64_t M, int64_t Mp, int64_t N, int D, int L, int U, int64_t pstride,
+                            int64_t gpstride, hipStream_t st);
 int launch_maf_backward_mfma(const float* z, const float* params, const float* masks, const float* g_zout,
                              const float* g_ld, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int D,
                              int L, int U, int64_t pstride, int64_t gpstride, hipStream_t st);

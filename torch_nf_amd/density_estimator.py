@@ -183,8 +183,8 @@ class NormFlow(DensityEstimator):
 
     def _ar_args(self):
         maf, bn = self.bijectors[0], self.bijectors[1]
-        return (maf._masks_for(torch.float32), bn.get_last_mean().detach(), bn.get_last_alpha().detach(), self.D,
-                self.num_layers, self.num_units)
+        mean, alpha = bn._stats_for(None)  # device copies, made once per version of the statistics
+        return (maf._masks_for(torch.float32), mean.detach(), alpha.detach(), self.D, self.num_layers, self.num_units)
 
     def _whole_flow(self):
         """Does the fused coupling path run as ONE kernel (the only one with a fused support stage)?"""
@@ -338,6 +338,9 @@ class NormFlow(DensityEstimator):
             if sup is not False and self._ar_fused_ok(z, params):
                 # ToInterval^-1 in the load stage of the one-kernel AR path
                 return ops.ar_flow_log_prob_raw(z, params, *self._ar_args(), interval_consts=sup)[0]
+            if sup is not False and self._ar_train_ok(z, params):
+                masks, mean, alpha, D, L, U = self._ar_args()
+                return ops.ar_flow_log_prob_train(z, params, masks, mean, alpha, sup, D, L, U)
             if sup is not False and self._fused_ok(z, params) and self._whole_flow():
                 mean, alpha = self._bn_stats(_lib.require_device())  # ... or of the whole-flow coupling kernel
                 return ops.flow_log_prob_raw(z, params, mean, alpha, self.D, self.num_stages, self.num_layers,
@@ -356,9 +359,21 @@ class NormFlow(DensityEstimator):
             return "layers"
         return None
 
+    def _ar_train_ok(self, z, params):
+        """Training through the AR stack with z a constant: one forward kernel, one backward kernel."""
+        return (self.arch_type == "AR" and getattr(self, "fused_ar_training", True) and torch.is_grad_enabled()
+                and params.requires_grad and not z.requires_grad and z.dim() == 3
+                and z.dtype == torch.float32 and params.dtype == torch.float32
+                and z.size(0) == max(z.size(0), params.size(0))
+                and ops.ar_flow_supported(self.D, self.num_layers, self.num_units)
+                and ops.ar_flow_train_supported(z.size(0), params.size(0), self.D, self.num_layers, self.num_units))
+
     def _core_log_prob(self, z, params):
         if self._ar_fused_ok(z, params):
             return ops.ar_flow_log_prob_raw(z, params, *self._ar_args())[0]
+        if self._ar_train_ok(z, params):
+            masks, mean, alpha, D, L, U = self._ar_args()
+            return ops.ar_flow_log_prob_train(z, params, masks, mean, alpha, None, D, L, U)
         if self._fused_ok(z, params):
             dev = _lib.require_device()
             mean, alpha = self._bn_stats(dev)

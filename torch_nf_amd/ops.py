@@ -787,6 +787,51 @@ def ar_flow_log_prob_raw(z, params, masks, bn_mean, bn_alpha, D, L, U, want_lp=T
     return lp, z0, sld
 
 
+def ar_flow_train_supported(M, Mp, D, L, U):
+    return Mp in (1, M) and lib.tnf_ar_flow_train_supported(D, L, U) == 1
+
+
+class _ArFlowLogProbFn(torch.autograd.Function):
+    """NormFlow('AR').log_prob with z a constant of the graph (the LFI scripts' training loop): the forward is the
+    one-kernel inference path (tnf_ar_flow_log_prob_f32), the backward ONE kernel for the whole stack
+    (tnf_ar_flow_log_prob_bwd_f32: ToInterval^-1, the folded Affine / BatchNorm, MAF recompute and backward,
+    base density) writing the gradient of every parameter slice into one buffer."""
+
+    @staticmethod
+    def forward(ctx, z, params, masks, bn_mean, bn_alpha, interval_consts, D, L, U):
+        lp, _, _ = ar_flow_log_prob_raw(z, params, masks, bn_mean, bn_alpha, D, L, U, interval_consts=interval_consts)
+        dev = _lib.require_device()
+        pc, pstride = _rows(params.detach(), dev)
+        ctx.save_for_backward(_stage(z.detach(), dev), pc,
+                              masks if (masks.device == dev and masks.dtype == torch.float32) else _stage(masks.float(), dev),
+                              _stats(bn_mean.reshape(-1), dev), _stats(bn_alpha.reshape(-1), dev))
+        ctx.consts = interval_consts
+        ctx.cfg = (D, L, U, pstride, params.device, tuple(params.shape))
+        return lp
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        zc, pc, mk, mean, alpha = ctx.saved_tensors
+        D, L, U, pstride, p_home, p_shape = ctx.cfg
+        dev = zc.device
+        M, N = zc.shape[0], zc.shape[1]
+        Mp = pc.shape[0]
+        g = _stage(g_lp.float(), dev)
+        gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+        nbytes = check(lib.tnf_ar_flow_bwd_workspace_bytes(Mp, D))
+        ws = _workspace(nbytes, dev)
+        check(lib.tnf_ar_flow_log_prob_bwd_f32(zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), mean.data_ptr(),
+                                               alpha.data_ptr(),
+                                               None if ctx.consts is None else ctx.consts.data_ptr(), g.data_ptr(),
+                                               gp.data_ptr(), M, Mp, N, D, L, U, pstride, gp.shape[1], ws.data_ptr(),
+                                               nbytes, _lib.stream_ptr()))
+        return None, (gp if p_home == dev else gp.to(p_home)), None, None, None, None, None, None, None
+
+
+def ar_flow_log_prob_train(z, params, masks, bn_mean, bn_alpha, interval_consts, D, L, U):
+    return _ArFlowLogProbFn.apply(z, params, masks, bn_mean, bn_alpha, interval_consts, D, L, U)
+
+
 def ar_flow_forward_raw(omega, params, masks, bn_mean, bn_alpha, D, L, U, interval_consts=None):
     """tnf_ar_flow_forward_f32 (cached BatchNorm statistics) -> (z, sum_log_det) on the compute device."""
     dev, zc, pc, pstride, mk, mean, alpha, Mz, Mp, M, N, ws, nbytes = _ar_common(omega, params, masks, bn_mean,
