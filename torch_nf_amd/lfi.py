@@ -20,14 +20,15 @@ import torch
 
 
 def _atom_indices(M, M_atom, device, generator=None):
-    """(M, M_atom) int64: column 0 is the row's own index, the others are M_atom - 1 distinct other rows."""
+    """(M, M_atom) int64: column 0 is the row's own index, the others are M_atom - 1 distinct other rows:
+    row i takes (i + o_k) mod M for one random set of distinct offsets o_k in [1, M - 1] drawn per call (a sort
+    of M - 1 uniforms instead of a top-k over an M x M score matrix, which cost more than the training step)."""
     M_atom = min(M_atom, M)
-    # random scores per (row, candidate); the own index is excluded by an infinite score, top-k picks the rest
-    scores = torch.rand((M, M), device=device, generator=generator)
-    scores.fill_diagonal_(2.0)
-    others = torch.topk(scores, M_atom - 1, dim=1, largest=False).indices
     own = torch.arange(M, device=device)[:, None]
-    return torch.cat((own, others), 1)
+    if M_atom <= 1:
+        return own
+    offsets = torch.rand(M - 1, device=device, generator=generator).argsort()[:M_atom - 1] + 1
+    return torch.cat((own, (own + offsets[None, :]) % M), 1)
 
 
 def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3, num_sims=None, verbose=False,
@@ -68,13 +69,14 @@ def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3,
         n = Z.shape[0]
         Mb = min(M, n)
         Z_r, X_r = Z, X  # this round's pairs: fixed addresses for the captured step
+        logp_r = system.log_prior(Z_r)  # the prior density of every stored parameter, once per round
 
         def step():
             idx = torch.randint(0, n, (Mb,), device=dev)
             z_b, x_b = Z_r[idx], X_r[idx]
             atoms = _atom_indices(Mb, M_atom, dev)
             z_atoms = z_b[atoms]                                  # (Mb, M_atom, D)
-            lp = cde.log_prob(z_atoms, x_b) - system.log_prior(z_atoms)
+            lp = cde.log_prob(z_atoms, x_b) - logp_r[idx][atoms]
             loss = -(lp[:, 0] - torch.logsumexp(lp, dim=1)).mean()
             opt.zero_grad(set_to_none=True)
             loss.backward()
