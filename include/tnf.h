@@ -340,6 +340,17 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
                               int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                               int64_t g_params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* NormFlow.forward with freeze_bn=False and no autograd (the default sampling call: density_estimator.py:374-388
+ * with the batch-statistics BatchNorm of bijectors.py:401-415) as ONE call: per coupling layer a fused kernel
+ * whose load stage applies the BatchNorm (and Affine) in front of it, then the batch statistics of its output.
+ * Outputs: z_out (M,N,D), sum_log_det (M,N) = sum of the forward log-dets, and the statistics every BatchNorm
+ * layer caches, bn_mean_out / bn_alpha_out (2*num_stages, D), forward order.  Statistics are over all M*N rows. */
+int64_t tnf_flow_forward_batch_workspace_bytes(int64_t M_p, int32_t D, int32_t num_stages, int32_t num_layers);
+int tnf_flow_forward_batch_f32(const float* omega, const float* params, float* z_out, float* sum_log_det,
+                               float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                               int32_t num_stages, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
+                               float eps, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Reversible training pair for the same loss (density_estimator.py:390-416 under autograd).  The
  * coupling stack is invertible, so the forward is the whole-flow kernel of tnf_flow_log_prob_f32
  * and keeps only its output z0 (M,N,D); the backward is ONE kernel that walks the layers from z0,

@@ -425,3 +425,30 @@ def test_hip_graph_capture(tnf, oracle):
         torch.cuda.synchronize()
     want = oracle.flow_log_prob(z_new, params, D, S, L, U, stats)
     torch.testing.assert_close(out_static.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("D,S,L,M,N", [(64, 4, 2, 1, 5000), (32, 2, 3, 3, 700), (64, 1, 1, 2, 33)])
+def test_batch_stats_forward_one_call_vs_per_bijector(tnf, D, S, L, M, N):
+    """NormFlow.forward(freeze_bn=False) without autograd: the one-call chain (tnf_flow_forward_batch_f32: BatchNorm
+    and Affine folded into the next coupling kernel, statistics over all M*N rows) against the per-bijector
+    composition -- samples, log-densities and the statistics every BatchNorm layer caches."""
+    U = 15
+    rng = np.random.RandomState(D + N)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    params = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float().cuda()
+    omega = rng.normal(0, 1, (M, N, D))
+    out = {}
+    for fused in (True, False):
+        nf.fused_batch_forward = fused
+        with torch.no_grad():
+            z, lq = nf._forward_from(omega, params, freeze_bn=False)
+        out[fused] = (z, lq, [b.get_last_mean().clone() for b in nf._bn_layers()],
+                      [b.get_last_alpha().clone() for b in nf._bn_layers()])
+    torch.testing.assert_close(out[True][0], out[False][0], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-6, atol=2e-4)
+    for a, b in zip(out[True][2] + out[True][3], out[False][2] + out[False][3]):
+        torch.testing.assert_close(a.cpu(), b.cpu(), rtol=2e-5, atol=2e-5)
+    # the cached statistics serve the frozen paths afterwards
+    with torch.no_grad():
+        lp = nf.log_prob(out[True][0], params)
+    torch.testing.assert_close(lp.double(), out[True][1], rtol=1e-5, atol=2e-3)

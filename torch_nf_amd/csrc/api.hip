@@ -871,6 +871,36 @@ int tnf_flow_log_prob_bwd_rev_f32(const float* z0, const float* params, const fl
                                gpstride, workspace, as_stream(stream));
 }
 
+// NormFlow.forward with batch-statistics BatchNorm (freeze_bn=False), no autograd: one C call for the whole stack
+int64_t tnf_flow_forward_batch_workspace_bytes(int64_t M_p, int32_t D, int32_t S, int32_t L) {
+    if (M_p < 1 || D < 2 || S < 1 || L < 1)
+        return fail(TNF_EINVAL, "tnf_flow_forward_batch_workspace_bytes: M_p=%lld D=%d S=%d L=%d", (long long)M_p, D, S, L);
+    return flow_forward_batch_workspace(M_p, D, S, L);
+}
+
+int tnf_flow_forward_batch_f32(const float* omega, const float* params, float* z_out, float* sum_log_det,
+                               float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                               int32_t S, int32_t L, int32_t U, int64_t pstride, float eps, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    const char* fn = "tnf_flow_forward_batch_f32";
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0 || S < 1)
+        return fail(TNF_EINVAL, "%s: M=%lld M_p=%lld N=%lld S=%d", fn, (long long)M, (long long)M_p, (long long)N, S);
+    if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "%s: no kernel for D=%d L=%d U=%d", fn, D, L, U);
+    if (M * N < 2) return fail(TNF_EINVAL, "%s: batch statistics need more than one row", fn);
+    if (pstride < flow_layout(D, S, L, U).total)
+        return fail(TNF_EINVAL, "%s: params row has %lld elements, flow needs %lld", fn, (long long)pstride,
+                    (long long)flow_layout(D, S, L, U).total);
+    if (!omega || !params || !z_out || !sum_log_det || !bn_mean_out || !bn_alpha_out || !workspace)
+        return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    if (!aligned16(omega) || !aligned16(z_out)) return fail(TNF_EINVAL, "%s: omega / z_out must be 16-byte aligned", fn);
+    if (z_out == omega) return fail(TNF_EINVAL, "%s: z_out must not alias omega", fn);
+    if (workspace_bytes < flow_forward_batch_workspace(M_p, D, S, L))
+        return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)workspace_bytes,
+                    (long long)flow_forward_batch_workspace(M_p, D, S, L));
+    return launch_flow_forward_batch(omega, params, z_out, sum_log_det, bn_mean_out, bn_alpha_out, M, M_p, N, D, S, L, U,
+                                     pstride, eps, workspace, as_stream(stream));
+}
+
 int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
                          const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
                          int64_t M_z,

@@ -127,12 +127,8 @@ int64_t mfma_image_floats(int D, int L) {
     return (int64_t)(4 * HT + 2 * (L - 1)) * 256 + (2 + 2 * (L - 1) + 2 * HT) * 16;
 }
 
-int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
-                     float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
-                     int64_t pstride, int inverse, hipStream_t st) {
-    hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
-                       bn_alpha, fold, ldc, D, S, L, U, pstride, inverse);
-    if (!images) return check_launch("flow_prep");  // wide shapes build their own images
+int launch_flow_images(const float* params, float* images, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
+                       hipStream_t st) {
     const dim3 grid = grid_xm(2 * S, Mp);
     const int64_t fl = mfma_image_floats(D, L);
 #define TNF_IMG(HH, LL) \
@@ -143,7 +139,16 @@ int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_
         if (L == 1) TNF_IMG(16, 1); else if (L == 2) TNF_IMG(16, 2); else TNF_IMG(16, 3);
     }
 #undef TNF_IMG
-    return check_launch("flow_prep");
+    return check_launch("flow_images");
+}
+
+int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
+                     float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
+                     int64_t pstride, int inverse, hipStream_t st) {
+    hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
+                       bn_alpha, fold, ldc, D, S, L, U, pstride, inverse);
+    if (!images) return check_launch("flow_prep");  // wide shapes build their own images
+    return launch_flow_images(params, images, Mp, D, S, L, U, pstride, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -402,6 +407,133 @@ int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st) {
     if (a.D == 64) launch_h<32>(a, M, st);
     else launch_h<16>(a, M, st);
     return check_launch("coupling_mfma");
+}
+
+// ---------------------------------------------------------------------------
+// NormFlow.forward with freeze_bn=False and no autograd (the reference's default sampling call,
+// density_estimator.py:374-388 with bijectors.py:401-415): every BatchNorm normalises with the statistics of the
+// batch in front of it, so a layer's output must be complete before the next one starts.  The chain keeps that
+// order but folds each BatchNorm (+ the Affine behind the second one of a stage) into the NEXT coupling
+// kernel's load stage:  per layer  coupling kernel (pre-fold) -> bn_stats -> bn_finalize -> fold constants,
+// and one elementwise pass at the end for the last fold.  The statistics land in bn_mean_out / bn_alpha_out
+// (2S, D) exactly as BatchNorm.forward(use_last=False) would cache them.
+// ---------------------------------------------------------------------------
+// fold after layer c (forward order): z -> (z - mean)/alpha [-> e^a z + shift when c is odd]; ldc[m] += its log-det
+__global__ void __launch_bounds__(256)
+flow_batch_fold_kernel(const float* __restrict__ params, int64_t pstride, int64_t affine_off, const float* __restrict__ mean,
+                       const float* __restrict__ rstd, const float* __restrict__ ld_bn, float* __restrict__ fold,
+                       float* __restrict__ ldc, int D, int has_affine, int first) {
+    const int64_t m = blockIdx.x;
+    const float* ap = params + m * pstride + affine_off;
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float rs = rstd[d], mu = mean[d];
+        float A = rs, B = -mu * rs;
+        if (has_affine) {
+            const float av = ap[d], ea = expf(av);
+            acc += av;
+            A = ea * rs;
+            B = ap[D + d] - mu * A;
+        }
+        fold[m * 2 * D + d] = A;
+        fold[m * 2 * D + D + d] = B;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ldc[m] = (first ? 0.f : ldc[m]) + red[0] + *ld_bn;
+}
+
+// z <- z A[m] + B[m] in place, sum_log_det[m][n] += ldc[m]
+__global__ void __launch_bounds__(256)
+flow_fold_apply_kernel(float* __restrict__ z, float* __restrict__ sld, const float* __restrict__ fold,
+                       const float* __restrict__ ldc, int64_t Mp, int64_t N, int D) {
+    const int64_t m = grid_m();
+    const int64_t mp = Mp == 1 ? 0 : m;
+    const float* A = fold + mp * 2 * D;
+    const float* B = A + D;
+    float* zr = z + m * N * D;
+    const int64_t total = N * D;
+    const int64_t step = (int64_t)gridDim.x * 1024;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += 4 * step) {
+        f4 v[4];  // four 16-byte accesses in flight per lane; D % 4 == 0: the four values of one share a row
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * step;
+            if (i < total) v[u] = *reinterpret_cast<f4*>(zr + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * step;
+            if (i < total) {
+                const int d = (int)(i % D);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[u][j] = __builtin_fmaf(v[u][j], A[d + j], B[d + j]);
+                *reinterpret_cast<f4*>(zr + i) = v[u];
+            }
+        }
+    }
+    const float c = ldc[mp];
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) sld[m * N + n] += c;
+}
+
+static int64_t fb_head_bytes(int64_t Mp, int D) { return (((Mp * 2 * D + Mp + D + 1) * 4 + 15) / 16) * 16; }
+int64_t flow_forward_batch_workspace(int64_t Mp, int D, int S, int L) {
+    // fold (Mp, 2, D) | ldc (Mp) | rstd (D) | ld_bn (1) | sums (2 D doubles) | operand images (Mp, 2S, image)
+    return fb_head_bytes(Mp, D) + 2 * (int64_t)D * 8 + Mp * 2 * S * mfma_image_floats(D, L) * 4;
+}
+
+int launch_flow_forward_batch(const float* omega, const float* params, float* z_out, float* sum_log_det,
+                              float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t Mp, int64_t N, int D, int S,
+                              int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st) {
+    if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "flow_forward_batch: D=%d L=%d U=%d", D, L, U);
+    if (N <= 0) return TNF_OK;
+    float* fold = reinterpret_cast<float*>(ws);
+    float* ldc = fold + Mp * 2 * D;
+    float* rstd = ldc + Mp;
+    float* ld_bn = rstd + D;
+    double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + fb_head_bytes(Mp, D));
+    float* images = reinterpret_cast<float*>(sums + 2 * D);
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const int nl = 2 * S;
+    const int64_t img_floats = mfma_image_floats(D, L);
+    {
+        int rc = launch_flow_images(params, images, Mp, D, S, L, U, pstride, st);
+        if (rc) return rc;
+    }
+    const int64_t rows = M * N;
+    for (int c = 0; c < nl; ++c) {
+        MfmaLayerArgs a = {};
+        a.z = c == 0 ? omega : z_out;
+        a.z_out = z_out;
+        a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+        a.pstride = pstride;
+        a.image = images + (int64_t)c * img_floats;
+        a.image_stride = (int64_t)nl * img_floats;
+        a.pre = c == 0 ? nullptr : fold;
+        a.fold_stride = 2 * (int64_t)D;
+        a.ld_in = c == 0 ? nullptr : sum_log_det;
+        a.ld_out = sum_log_det;
+        a.ld_sign = 1.f;
+        a.Mz = M; a.Mp = Mp; a.N = N;
+        a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 0;
+        int rc = launch_coupling_mfma(a, st);
+        if (rc) return rc;
+        rc = launch_bn_stats(z_out, sums, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D, rstd, ld_bn, rows, D,
+                             eps, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(flow_batch_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
+                           (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, bn_mean_out + (int64_t)c * D, rstd, ld_bn,
+                           fold, ldc, D, c & 1, c == 0);
+    }
+    int64_t nb = (N * D / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(flow_fold_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, z_out, sum_log_det, fold, ldc, Mp, N, D);
+    return check_launch("flow_forward_batch");
 }
 
 }  // namespace tnf

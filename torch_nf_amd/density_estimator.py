@@ -269,6 +269,16 @@ class NormFlow(DensityEstimator):
                                           interval_consts=sup if fuse_sup else None)
             log_q = log_q - sld
             support_done = fuse_sup
+        elif (not freeze_bn and self._fused_ok(z, p_dev) and z.dim() == 3 and z.size(0) == p_dev.size(0)
+              and z.size(0) * z.size(1) > 1 and getattr(self, "fused_batch_forward", True)):
+            # fresh batch statistics, no autograd: one call for the whole stack; every BatchNorm layer ends up with
+            # the statistics its own forward(use_last=False) would have cached
+            bns = self._bn_layers()
+            z, sld, means, alphas = ops.flow_forward_batch_raw(z, p_dev, self.D, self.num_stages, self.num_layers,
+                                                               self.num_units, bns[0].eps)
+            for i, b in enumerate(bns):
+                b.set_last_stats(means[i], alphas[i])
+            log_q = log_q - sld
         else:
             idx = 0
             for bijector in self.bijectors[:self._n_core]:

@@ -373,6 +373,26 @@ def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.F
 # flow level, with autograd: log_prob through one fused kernel per layer, backward through one
 # MFMA backward kernel per layer (tnf_flow_log_prob_fwd_f32 / _bwd_f32)
 # ---------------------------------------------------------------------------
+def flow_forward_batch_raw(omega, params, D, S, L, U, eps):
+    """tnf_flow_forward_batch_f32: NormFlow.forward with batch-statistics BatchNorm and no autograd in one call
+    -> (z, sum_log_det, bn_mean (2S, D), bn_alpha (2S, D)), all on the compute device."""
+    dev = _lib.require_device()
+    oc = _stage(omega.detach(), dev)
+    pc, pstride = _rows(params.detach(), dev)
+    M, N = oc.shape[0], oc.shape[1]
+    Mp = pc.shape[0]
+    z = torch.empty_like(oc)
+    sld = torch.empty((M, N), dtype=torch.float32, device=dev)
+    mean = torch.empty((2 * S, D), dtype=torch.float32, device=dev)
+    alpha = torch.empty((2 * S, D), dtype=torch.float32, device=dev)
+    nbytes = check(lib.tnf_flow_forward_batch_workspace_bytes(Mp, D, S, L))
+    ws = _workspace(nbytes, dev)
+    check(lib.tnf_flow_forward_batch_f32(oc.data_ptr(), pc.data_ptr(), z.data_ptr(), sld.data_ptr(), mean.data_ptr(),
+                                         alpha.data_ptr(), M, Mp, N, D, S, L, U, pstride, float(eps), ws.data_ptr(),
+                                         nbytes, _lib.stream_ptr()))
+    return z, sld, mean, alpha
+
+
 def flow_train_supported(M, Mp, N, D, S, L, U):
     return Mp in (1, M) and N >= 32 and lib.tnf_flow_train_workspace_bytes(M, Mp, max(N, 1), D, S, L, U) >= 0
 
