@@ -351,6 +351,25 @@ int tnf_flow_forward_batch_f32(const float* omega, const float* params, float* z
                                int32_t num_stages, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                                float eps, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same call under autograd (objectives on samples z = nf(N) and their log-density, e.g. the reference's
+ * train_efn loop, with fresh batch statistics).  Forward: as above, out of place -- states (2*num_stages, M,N,D)
+ * keeps every coupling layer's output before the fold behind it, folds (2*num_stages, M_p, 2, D) that fold's
+ * constants.  Backward: given g_z (M,N,D) and g_sum_log_det (M,N), one coupling backward kernel per layer (its
+ * per-context fold sums are the sums the batch-statistics backward needs) plus the fold's own backward -- gradients
+ * through the batch mean and variance included; g_params (M_p rows, accumulated, zero it first), g_omega optional. */
+int64_t tnf_flow_forward_train_workspace_bytes(int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t num_stages,
+                                               int32_t num_layers);
+int tnf_flow_forward_train_fwd_f32(const float* omega, const float* params, float* z_out, float* sum_log_det,
+                                   float* states, float* folds, float* bn_mean_out, float* bn_alpha_out, int64_t M,
+                                   int64_t M_p, int64_t N, int32_t D, int32_t num_stages, int32_t num_layers,
+                                   int32_t num_units, int64_t params_row_stride, float eps, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
+int tnf_flow_forward_train_bwd_f32(const float* omega, const float* params, const float* states, const float* folds,
+                                   const float* bn_mean, const float* bn_alpha, const float* g_z, const float* g_sum_log_det,
+                                   float* g_omega, float* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                                   int32_t num_stages, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
+                                   int64_t g_params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Reversible training pair for the same loss (density_estimator.py:390-416 under autograd).  The
  * coupling stack is invertible, so the forward is the whole-flow kernel of tnf_flow_log_prob_f32
  * and keeps only its output z0 (M,N,D); the backward is ONE kernel that walks the layers from z0,

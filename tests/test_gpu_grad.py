@@ -249,3 +249,56 @@ def test_flow_reversible_backward_zero_upstream(tnf):
     z = torch.randn(1, N, D).cuda().requires_grad_()
     (nf.log_prob(z, p) * 0.0).sum().backward()
     assert float(p.grad.abs().max()) == 0.0 and float(z.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("D,S,L,M,N", [(64, 4, 2, 1, 600), (32, 2, 3, 3, 100), (64, 1, 1, 2, 40)])
+def test_forward_path_training_one_node(tnf, oracle, D, S, L, M, N):
+    """Sampling with fresh batch statistics under autograd as ONE node (tnf_flow_forward_train_fwd/bwd_f32: the
+    BatchNorm / Affine between coupling layers folded into the next kernel, gradients through the batch moments
+    from the coupling backward kernels' fold sums): loss and gradients w.r.t. the parameter rows and the base draw
+    against (a) the per-bijector autograd path and (b) torch autograd over the oracle."""
+    U = 15
+    rng = np.random.RandomState(D + N)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float()
+    om0 = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+    w = torch.tensor(rng.uniform(0.5, 1.5, (M, N))).float()
+    res = {}
+    for fused in (True, False):
+        nf.fused_batch_forward = fused
+        p = p0.clone().cuda().requires_grad_()
+        z, lq = nf._forward_from(om0.cuda(), p, freeze_bn=False)  # the base draw is a constant of this call
+        loss = (lq * w.cuda()).mean() + (z ** 2).mean()
+        loss.backward()
+        res[fused] = (loss.detach().cpu(), p.grad.cpu(), [b.get_last_alpha().cpu().clone() for b in nf._bn_layers()])
+    # the node itself also differentiates w.r.t. the base draw
+    p = p0.clone().cuda().requires_grad_()
+    om = om0.clone().cuda().requires_grad_()
+    z, sld, _, _ = tnf.ops.flow_forward_train(om, p, D, S, L, U, 1e-5)
+    lq = tnf.ops.base_log_density_f64(om.detach()) - sld
+    ((lq * w.cuda()).mean() + (z ** 2).mean()).backward()
+    p_ref = p0.clone().requires_grad_()
+    z_r, lq_r, _ = oracle.flow_forward(om0.double().numpy(), p_ref, D, S, L, U, None)
+    loss_r = (lq_r * w).mean() + (z_r ** 2).mean()
+    loss_r.backward()
+    sp = float(p_ref.grad.abs().max())
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(res[True][0].double(), loss_r.detach().double(), rtol=1e-5, atol=1e-5)
+    for a, b in zip(res[True][2], res[False][2]):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-3, atol=1e-4 * sp)
+    torch.testing.assert_close(res[True][1], p_ref.grad, rtol=5e-3, atol=2e-4 * sp)
+    torch.testing.assert_close(p.grad.cpu(), p_ref.grad, rtol=5e-3, atol=2e-4 * sp)
+    # d loss / d omega: finite differences of the oracle along one random direction (the oracle takes omega as numpy)
+    dirn = torch.tensor(np.random.RandomState(1).normal(0, 1, om0.shape)).float()
+    h = 1e-3
+
+    def oracle_loss(o):
+        zz, ll, _ = oracle.flow_forward(o.double().numpy(), p0, D, S, L, U, None)
+        # the base density is a function of omega too; the node returns only z and sum_log_det, so compare that part
+        base = torch.tensor(oracle.base_log_density_f64(o.double().numpy()))
+        return float((((ll - base) * w).mean() + (zz ** 2).mean()).double())
+
+    fd = (oracle_loss(om0 + h * dirn) - oracle_loss(om0 - h * dirn)) / (2 * h)
+    got = float((om.grad.cpu() * dirn).sum())
+    assert abs(got - fd) <= 2e-2 * max(1.0, abs(fd)), (got, fd)

@@ -901,6 +901,62 @@ int tnf_flow_forward_batch_f32(const float* omega, const float* params, float* z
                                      pstride, eps, workspace, as_stream(stream));
 }
 
+// ... and the same stack under autograd (sampling-based objectives): forward keeps every coupling layer's output
+int64_t tnf_flow_forward_train_workspace_bytes(int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L) {
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0 || D < 2 || S < 1 || L < 1)
+        return fail(TNF_EINVAL, "tnf_flow_forward_train_workspace_bytes: M=%lld M_p=%lld N=%lld D=%d S=%d L=%d",
+                    (long long)M, (long long)M_p, (long long)N, D, S, L);
+    return flow_forward_train_workspace(M, M_p, N, D, S, L);
+}
+
+static int fwd_train_checks(const char* fn, int64_t M, int64_t M_p, int64_t N, int D, int S, int L, int U, int64_t pstride,
+                            const void* ws, int64_t ws_bytes) {
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0 || S < 1)
+        return fail(TNF_EINVAL, "%s: M=%lld M_p=%lld N=%lld S=%d", fn, (long long)M, (long long)M_p, (long long)N, S);
+    if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "%s: no kernel for D=%d L=%d U=%d", fn, D, L, U);
+    if (M * N < 2) return fail(TNF_EINVAL, "%s: batch statistics need more than one row", fn);
+    if (pstride < flow_layout(D, S, L, U).total)
+        return fail(TNF_EINVAL, "%s: params row has %lld elements, flow needs %lld", fn, (long long)pstride,
+                    (long long)flow_layout(D, S, L, U).total);
+    if (!ws || ws_bytes < flow_forward_train_workspace(M, M_p, N, D, S, L))
+        return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)ws_bytes,
+                    (long long)flow_forward_train_workspace(M, M_p, N, D, S, L));
+    return TNF_OK;
+}
+
+int tnf_flow_forward_train_fwd_f32(const float* omega, const float* params, float* z_out, float* sum_log_det,
+                                   float* states, float* folds, float* bn_mean_out, float* bn_alpha_out, int64_t M,
+                                   int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U, int64_t pstride,
+                                   float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* fn = "tnf_flow_forward_train_fwd_f32";
+    int rc = fwd_train_checks(fn, M, M_p, N, D, S, L, U, pstride, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!omega || !params || !z_out || !sum_log_det || !states || !folds || !bn_mean_out || !bn_alpha_out)
+        return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    if (!aligned16(omega) || !aligned16(z_out) || !aligned16(states))
+        return fail(TNF_EINVAL, "%s: omega / z_out / states must be 16-byte aligned", fn);
+    return launch_flow_forward_train_fwd(omega, params, z_out, sum_log_det, states, folds, bn_mean_out, bn_alpha_out, M, M_p,
+                                         N, D, S, L, U, pstride, eps, workspace, as_stream(stream));
+}
+
+int tnf_flow_forward_train_bwd_f32(const float* omega, const float* params, const float* states, const float* folds,
+                                   const float* bn_mean, const float* bn_alpha, const float* g_z, const float* g_sum_log_det,
+                                   float* g_omega, float* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t S,
+                                   int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    const char* fn = "tnf_flow_forward_train_bwd_f32";
+    int rc = fwd_train_checks(fn, M, M_p, N, D, S, L, U, pstride, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!omega || !params || !states || !folds || !bn_mean || !bn_alpha || !g_z || !g_sum_log_det || !g_params)
+        return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    if (gpstride < flow_layout(D, S, L, U).total) return fail(TNF_EINVAL, "%s: g_params row too short", fn);
+    if (!aligned16(omega) || !aligned16(states) || !aligned16(g_z) || (g_omega && !aligned16(g_omega)) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(TNF_EINVAL, "%s: omega / states / g_z / g_omega must be 16-byte and the workspace 256-byte aligned", fn);
+    return launch_flow_forward_train_bwd(omega, params, states, folds, bn_mean, bn_alpha, g_z, g_sum_log_det, g_omega,
+                                         g_params, M, M_p, N, D, S, L, U, pstride, gpstride, workspace, as_stream(stream));
+}
+
 int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
                          const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
                          int64_t M_z,

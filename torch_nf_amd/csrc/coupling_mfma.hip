@@ -3,6 +3,7 @@
 // BatchNorm / Affine bijectors folded in as per-feature FMAs and, on the last layer
 // of a log_prob chain, the base Gaussian density.  HBM traffic per sample and launch:
 // read D floats + write D floats (+ 8 B of running log-det), i.e. 520 B at D = 64.
+#include <cstring>
 #include "mfma_tile.h"
 #include "tnf_common.h"
 
@@ -448,15 +449,16 @@ flow_batch_fold_kernel(const float* __restrict__ params, int64_t pstride, int64_
     if (threadIdx.x == 0) ldc[m] = (first ? 0.f : ldc[m]) + red[0] + *ld_bn;
 }
 
-// z <- z A[m] + B[m] in place, sum_log_det[m][n] += ldc[m]
+// z_out <- z A[m] + B[m] (z_out may be z), sum_log_det[m][n] += ldc[m]
 __global__ void __launch_bounds__(256)
-flow_fold_apply_kernel(float* __restrict__ z, float* __restrict__ sld, const float* __restrict__ fold,
+flow_fold_apply_kernel(const float* z, float* z_out, float* __restrict__ sld, const float* __restrict__ fold,
                        const float* __restrict__ ldc, int64_t Mp, int64_t N, int D) {
     const int64_t m = grid_m();
     const int64_t mp = Mp == 1 ? 0 : m;
     const float* A = fold + mp * 2 * D;
     const float* B = A + D;
-    float* zr = z + m * N * D;
+    const float* zr = z + m * N * D;
+    float* zo = z_out + m * N * D;
     const int64_t total = N * D;
     const int64_t step = (int64_t)gridDim.x * 1024;
     for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += 4 * step) {
@@ -464,7 +466,7 @@ flow_fold_apply_kernel(float* __restrict__ z, float* __restrict__ sld, const flo
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t i = i0 + u * step;
-            if (i < total) v[u] = *reinterpret_cast<f4*>(zr + i);
+            if (i < total) v[u] = *reinterpret_cast<const f4*>(zr + i);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -473,7 +475,7 @@ flow_fold_apply_kernel(float* __restrict__ z, float* __restrict__ sld, const flo
                 const int d = (int)(i % D);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[u][j] = __builtin_fmaf(v[u][j], A[d + j], B[d + j]);
-                *reinterpret_cast<f4*>(zr + i) = v[u];
+                *reinterpret_cast<f4*>(zo + i) = v[u];
             }
         }
     }
@@ -532,8 +534,258 @@ int launch_flow_forward_batch(const float* omega, const float* params, float* z_
     }
     int64_t nb = (N * D / 4 + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(flow_fold_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, z_out, sum_log_det, fold, ldc, Mp, N, D);
+    hipLaunchKernelGGL(flow_fold_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, z_out, z_out, sum_log_det, fold, ldc, Mp,
+                       N, D);
     return check_launch("flow_forward_batch");
+}
+
+// ---------------------------------------------------------------------------
+// The same stack WITH autograd (sampling-based objectives: loss on z = nf(N) and its log-density with fresh
+// batch statistics).  Forward: the chain above run out of place -- states[c] = output of coupling layer c before
+// the fold behind it, folds[c] = that fold's constants.  Backward: per layer one coupling_bwd_mfma launch (its
+// fold gradients dA = sum g x_saved, dB = sum g per context are exactly the sums the batch-statistics backward
+// needs), then the fold's own backward:
+//   x = (v - mu) r e + sh,  mu = mean(v), r = 1/sqrt(var_b(v) + eps) over all R = M N rows, e = exp(a), per feature
+//   g_a = e r (P - mu Q) + S_m,  g_sh = Q                       (P = sum_n g_x v, Q = sum_n g_x, S_m = sum_n g_sld)
+//   g_r = sum_m e (P - mu Q) + (sum_m S_m)/r,  g_mu = -r sum_m e Q      (sum_log_det carries -log alpha = log r)
+//   g_v = g_x r e + k0 + k1 v,  k1 = -g_r r^3 / R,  k0 = g_mu / R - k1 mu
+// ---------------------------------------------------------------------------
+// per-context sums over the samples: PQ[mp] += [sum g v (D) | sum g (D)];  S[mp] += sum g_sld (when sld given)
+__global__ void __launch_bounds__(256)
+fold_sums_kernel(const float* __restrict__ g, const float* __restrict__ v, const float* __restrict__ g_sld,
+                 float* __restrict__ PQ, float* __restrict__ Ssum, int64_t Mp, int64_t N, int D, int64_t rows_per_block) {
+    __shared__ float red[256 * 2];
+    const int64_t m = grid_m();
+    const int64_t mp = Mp == 1 ? 0 : m;
+    const int tid = threadIdx.x;
+    const int rpi = 256 / D > 0 ? 256 / D : 1;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int dc = 0; dc < D; dc += 256) {
+        const int Dc = (D - dc) < 256 ? (D - dc) : 256;
+        const int rp = 256 / Dc;
+        const int r = tid / Dc, d = tid - r * Dc;
+        float p = 0.f, q = 0.f;
+        if (r < rp)
+            for (int64_t row = r0 + r; row < r1; row += rp) {
+                const float gv = g[(m * N + row) * D + dc + d];
+                p = fmaf(gv, v[(m * N + row) * D + dc + d], p);
+                q += gv;
+            }
+        red[tid] = p;
+        red[256 + tid] = q;
+        __syncthreads();
+        if (tid < Dc) {
+            float a = 0.f, b = 0.f;
+            for (int rr = 0; rr < rp; ++rr) {
+                a += red[rr * Dc + tid];
+                b += red[256 + rr * Dc + tid];
+            }
+            atomicAdd(PQ + mp * 2 * D + dc + tid, a);
+            atomicAdd(PQ + mp * 2 * D + D + dc + tid, b);
+        }
+        __syncthreads();
+    }
+    (void)rpi;
+    if (g_sld) {
+        float sacc = 0.f;
+        for (int64_t row = r0 + tid; row < r1; row += 256) sacc += g_sld[m * N + row];
+        red[tid] = sacc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) atomicAdd(Ssum + mp, red[0]);
+    }
+}
+
+// one block: the backward of the fold behind layer c.  kk: [k0 (D) | k1 (D)]
+__global__ void __launch_bounds__(256)
+fold_backward_kernel(const float* __restrict__ params, int64_t pstride, int64_t affine_off, const float* __restrict__ mean,
+                     const float* __restrict__ alpha, const float* __restrict__ PQ, const float* __restrict__ Ssum,
+                     float* __restrict__ g_params, int64_t gpstride, float* __restrict__ kk, int64_t Mp, double rows,
+                     int D, int has_affine) {
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float mu = mean[d], r = 1.f / alpha[d];
+        double g_r = 0.0, g_mu = 0.0, s_all = 0.0;
+        for (int64_t m = 0; m < Mp; ++m) {
+            const float P = PQ[m * 2 * D + d], Q = PQ[m * 2 * D + D + d];
+            float e = 1.f;
+            if (has_affine) {
+                e = expf(params[m * pstride + affine_off + d]);
+                atomicAdd(g_params + m * gpstride + affine_off + d, e * r * (P - mu * Q) + Ssum[m]);
+                atomicAdd(g_params + m * gpstride + affine_off + D + d, Q);
+            }
+            g_r += (double)e * ((double)P - (double)mu * (double)Q);
+            g_mu -= (double)e * (double)Q;
+            s_all += (double)Ssum[m];
+        }
+        // (with one shared parameter row, PQ[0] and Ssum[0] already hold the sums over all M sample batches)
+        g_r += s_all / (double)r;
+        g_mu *= (double)r;
+        const double k1 = -g_r * (double)r * (double)r * (double)r / rows;
+        kk[D + d] = (float)k1;
+        kk[d] = (float)(g_mu / rows - k1 * (double)mu);
+    }
+}
+
+// g_out = g_in A[m] + k0 + k1 v   (fold == NULL: A = 1);  g_out may alias g_in
+__global__ void __launch_bounds__(256)
+fold_bwd_apply_kernel(const float* g_in, const float* __restrict__ v, const float* __restrict__ fold,
+                      const float* __restrict__ kk, float* g_out, int64_t Mp, int64_t N, int D) {
+    const int64_t m = grid_m();
+    const int64_t mp = Mp == 1 ? 0 : m;
+    const float* A = fold ? fold + mp * 2 * D : nullptr;
+    const int64_t total = N * D, base = m * N * D;
+    const int64_t step = (int64_t)gridDim.x * 1024;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += 2 * step) {
+        f4 gv[2], vv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * step;
+            if (i < total) {
+                gv[u] = *reinterpret_cast<const f4*>(g_in + base + i);
+                vv[u] = *reinterpret_cast<const f4*>(v + base + i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * step;
+            if (i < total) {
+                const int d = (int)(i % D);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    gv[u][j] = __builtin_fmaf(gv[u][j], A ? A[d + j] : 1.f, __builtin_fmaf(kk[D + d + j], vv[u][j], kk[d + j]));
+                *reinterpret_cast<f4*>(g_out + base + i) = gv[u];
+            }
+        }
+    }
+}
+
+int64_t flow_forward_train_workspace(int64_t M, int64_t Mp, int64_t N, int D, int S, int L) {
+    // forward: as flow_forward_batch.  backward: PQ (Mp, 2, D) | S (Mp) | kk (2 D) | images | 2 x g buffers (M, N, D)
+    const int64_t fwd = flow_forward_batch_workspace(Mp, D, S, L);
+    const int64_t bwd = (((Mp * 2 * D + Mp + 2 * D) * 4 + 255) / 256) * 256 + Mp * 2 * S * mfma_image_floats(D, L) * 4 +
+                        2 * (((M * N * D * 4) + 255) / 256) * 256 + 256;
+    return fwd > bwd ? fwd : bwd;
+}
+
+int launch_flow_forward_train_fwd(const float* omega, const float* params, float* z_out, float* sum_log_det, float* states,
+                                  float* folds, float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t Mp, int64_t N,
+                                  int D, int S, int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st) {
+    if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "flow_forward_train: D=%d L=%d U=%d", D, L, U);
+    if (N <= 0) return TNF_OK;
+    float* ldc = reinterpret_cast<float*>(ws) + Mp * 2 * D;
+    float* rstd = ldc + Mp;
+    float* ld_bn = rstd + D;
+    double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + fb_head_bytes(Mp, D));
+    float* images = reinterpret_cast<float*>(sums + 2 * D);
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const int nl = 2 * S;
+    const int64_t img_floats = mfma_image_floats(D, L), plane = M * N * D;
+    int rc = launch_flow_images(params, images, Mp, D, S, L, U, pstride, st);
+    if (rc) return rc;
+    for (int c = 0; c < nl; ++c) {
+        MfmaLayerArgs a = {};
+        a.z = c == 0 ? omega : states + (int64_t)(c - 1) * plane;
+        a.z_out = states + (int64_t)c * plane;
+        a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+        a.pstride = pstride;
+        a.image = images + (int64_t)c * img_floats;
+        a.image_stride = (int64_t)nl * img_floats;
+        a.pre = c == 0 ? nullptr : folds + (int64_t)(c - 1) * Mp * 2 * D;
+        a.fold_stride = 2 * (int64_t)D;
+        a.ld_in = c == 0 ? nullptr : sum_log_det;
+        a.ld_out = sum_log_det;
+        a.ld_sign = 1.f;
+        a.Mz = M; a.Mp = Mp; a.N = N;
+        a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 0;
+        rc = launch_coupling_mfma(a, st);
+        if (rc) return rc;
+        rc = launch_bn_stats(states + (int64_t)c * plane, sums, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D,
+                             rstd, ld_bn, M * N, D, eps, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(flow_batch_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
+                           (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, bn_mean_out + (int64_t)c * D, rstd, ld_bn,
+                           folds + (int64_t)c * Mp * 2 * D, ldc, D, c & 1, c == 0);
+    }
+    int64_t nb = (N * D / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(flow_fold_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, states + (int64_t)(nl - 1) * plane, z_out,
+                       sum_log_det, folds + (int64_t)(nl - 1) * Mp * 2 * D, ldc, Mp, N, D);
+    return check_launch("flow_forward_train_fwd");
+}
+
+int launch_flow_forward_train_bwd(const float* omega, const float* params, const float* states, const float* folds,
+                                  const float* bn_mean, const float* bn_alpha, const float* g_z, const float* g_sld,
+                                  float* g_omega, float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L,
+                                  int U, int64_t pstride, int64_t gpstride, void* ws, hipStream_t st) {
+    if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "flow_forward_train: D=%d L=%d U=%d", D, L, U);
+    if (N <= 0) return TNF_OK;
+    char* wsb = reinterpret_cast<char*>(ws);
+    float* PQ = reinterpret_cast<float*>(wsb);
+    float* Ssum = PQ + Mp * 2 * D;
+    float* kk = Ssum + Mp;
+    const int64_t head = (((Mp * 2 * D + Mp + 2 * D) * 4 + 255) / 256) * 256;
+    float* images = reinterpret_cast<float*>(wsb + head);
+    const int nl = 2 * S;
+    const int64_t img_floats = mfma_image_floats(D, L), plane = M * N * D;
+    const int64_t gb = ((plane * 4 + 255) / 256) * 256;
+    char* gbase = wsb + head + ((Mp * nl * img_floats * 4 + 255) / 256) * 256;
+    float* gbuf[2] = {reinterpret_cast<float*>(gbase), reinterpret_cast<float*>(gbase + gb)};
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    int rc = launch_flow_images(params, images, Mp, D, S, L, U, pstride, st);
+    if (rc) return rc;
+    int64_t nb = (N * D / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    int64_t sb = (N + 255) / 256;
+    if (sb > 256) sb = 256;
+    const int64_t rpb = (N + sb - 1) / sb;
+    const double rows = (double)M * (double)N;
+    // ---- the last fold (behind layer nl-1): sums over (g_z, v), then g_v ----
+    if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D + Mp) * sizeof(float), st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "flow_forward_train_bwd: memset failed");
+    const float* v_last = states + (int64_t)(nl - 1) * plane;
+    hipLaunchKernelGGL(fold_sums_kernel, grid_xm(sb, M), dim3(256), 0, st, g_z, v_last, g_sld, PQ, Ssum, Mp, N, D, rpb);
+    int cur = 0;
+    for (int c = nl - 1; c >= 0; --c) {
+        // fold behind layer c: PQ holds its sums (from fold_sums for the last one, else from the layer c+1 backward)
+        const float* g_in = (c == nl - 1) ? g_z : gbuf[cur];
+        const int64_t aff = (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low;
+        hipLaunchKernelGGL(fold_backward_kernel, dim3(1), dim3(256), 0, st, params, pstride, aff, bn_mean + (int64_t)c * D,
+                           bn_alpha + (int64_t)c * D, PQ, Ssum, g_params, gpstride, kk, Mp, rows, D, c & 1);
+        // g wrt v_c: the last fold still has to apply A; the inner ones got it from the coupling backward already
+        hipLaunchKernelGGL(fold_bwd_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, g_in, states + (int64_t)c * plane,
+                           (c == nl - 1) ? folds + (int64_t)c * Mp * 2 * D : nullptr, kk, gbuf[cur ^ 1], Mp, N, D);
+        cur ^= 1;
+        // coupling layer c
+        if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D) * sizeof(float), st) != hipSuccess)
+            return fail(TNF_ELAUNCH, "flow_forward_train_bwd: memset failed");
+        BwdArgs a;
+        memset(&a, 0, sizeof(a));
+        const int64_t poff = (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
+        a.z = c == 0 ? omega : states + (int64_t)(c - 1) * plane;
+        a.params = params + poff;
+        a.g_zout = gbuf[cur];
+        a.g_ld = g_sld;
+        a.ld_scale = 1.f;
+        a.g_z = (c == 0 && g_omega) ? g_omega : gbuf[cur ^ 1];
+        a.g_params = g_params + poff;
+        a.M = M; a.Mp = Mp; a.N = N;
+        a.pstride = pstride; a.gpstride = gpstride;
+        a.U = U; a.upper = (c & 1) ? 0 : 1;
+        a.image = images + (int64_t)c * img_floats;
+        a.image_stride = (int64_t)nl * img_floats;
+        a.fold = c == 0 ? nullptr : folds + (int64_t)(c - 1) * Mp * 2 * D;
+        a.g_fold = c == 0 ? nullptr : PQ;
+        a.fold_stride = 2 * (int64_t)D;
+        rc = launch_coupling_backward_mfma_args(a, D, L, 0, st);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return check_launch("flow_forward_train_bwd");
 }
 
 }  // namespace tnf

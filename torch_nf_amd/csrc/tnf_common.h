@@ -136,6 +136,14 @@ int64_t flow_forward_batch_workspace(int64_t Mp, int D, int S, int L);
 int launch_flow_forward_batch(const float* omega, const float* params, float* z_out, float* sum_log_det,
                               float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t Mp, int64_t N, int D, int S,
                               int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st);
+int64_t flow_forward_train_workspace(int64_t M, int64_t Mp, int64_t N, int D, int S, int L);
+int launch_flow_forward_train_fwd(const float* omega, const float* params, float* z_out, float* sum_log_det, float* states,
+                                  float* folds, float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t Mp, int64_t N,
+                                  int D, int S, int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st);
+int launch_flow_forward_train_bwd(const float* omega, const float* params, const float* states, const float* folds,
+                                  const float* bn_mean, const float* bn_alpha, const float* g_z, const float* g_sld,
+                                  float* g_omega, float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S, int L,
+                                  int U, int64_t pstride, int64_t gpstride, void* ws, hipStream_t st);
 // reversible whole-flow training backward (flow_bwd_f16.hip)
 int flow_train_rev_supported(int D, int S, int L, int U);
 int64_t flow_train_rev_workspace(int64_t Mp, int D, int S, int L);

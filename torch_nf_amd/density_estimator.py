@@ -198,6 +198,12 @@ class NormFlow(DensityEstimator):
         sup = self.bijectors[-1]
         return sup._device_consts() if sup.name == "ToInterval" else False
 
+    def _batch_chain_ok(self, z, params):
+        """Shapes of the one-call chains with fresh batch statistics (the narrow MFMA layer kernels)."""
+        return (getattr(self, "fused_batch_forward", True) and z.dim() == 3 and z.size(0) == params.size(0)
+                and ops.flow_train_supported(z.size(0), params.size(0), 32, self.D, self.num_stages, self.num_layers,
+                                             self.num_units))
+
     def _fused_ok(self, z, params):
         """One-call fused path: coupling stack, float32, no autograd, MFMA-covered shape."""
         if self.arch_type != "coupling":
@@ -269,13 +275,23 @@ class NormFlow(DensityEstimator):
                                           interval_consts=sup if fuse_sup else None)
             log_q = log_q - sld
             support_done = fuse_sup
-        elif (not freeze_bn and self._fused_ok(z, p_dev) and z.dim() == 3 and z.size(0) == p_dev.size(0)
-              and z.size(0) * z.size(1) > 1 and getattr(self, "fused_batch_forward", True)):
+        elif (not freeze_bn and self._fused_ok(z, p_dev) and self._batch_chain_ok(z, p_dev)
+              and z.size(0) * z.size(1) > 1):
             # fresh batch statistics, no autograd: one call for the whole stack; every BatchNorm layer ends up with
             # the statistics its own forward(use_last=False) would have cached
             bns = self._bn_layers()
             z, sld, means, alphas = ops.flow_forward_batch_raw(z, p_dev, self.D, self.num_stages, self.num_layers,
                                                                self.num_units, bns[0].eps)
+            for i, b in enumerate(bns):
+                b.set_last_stats(means[i], alphas[i])
+            log_q = log_q - sld
+        elif (not freeze_bn and self.arch_type == "coupling" and z.dtype == torch.float32
+              and p_dev.dtype == torch.float32 and self._batch_chain_ok(z, p_dev) and z.size(0) * z.size(1) >= 32):
+            # fresh batch statistics under autograd: one node for the whole stack (gradients through the batch
+            # moments included)
+            bns = self._bn_layers()
+            z, sld, means, alphas = ops.flow_forward_train(z, p_dev, self.D, self.num_stages, self.num_layers,
+                                                           self.num_units, bns[0].eps)
             for i, b in enumerate(bns):
                 b.set_last_stats(means[i], alphas[i])
             log_q = log_q - sld

@@ -393,6 +393,61 @@ def flow_forward_batch_raw(omega, params, D, S, L, U, eps):
     return z, sld, mean, alpha
 
 
+class _FlowForwardTrainFn(torch.autograd.Function):
+    """NormFlow.forward with fresh batch statistics under autograd (tnf_flow_forward_train_fwd_f32 / _bwd_f32): one
+    node for the whole stack.  Returns (z, sum_log_det, bn_mean, bn_alpha); the statistics are not differentiable
+    outputs (the BatchNorm layers cache them detached, as everywhere in this package)."""
+
+    @staticmethod
+    def forward(ctx, omega, params, D, S, L, U, eps):
+        dev = _lib.require_device()
+        oc = _stage(omega.detach(), dev)
+        pc, pstride = _rows(params.detach(), dev)
+        M, N = oc.shape[0], oc.shape[1]
+        Mp = pc.shape[0]
+        z = torch.empty_like(oc)
+        sld = torch.empty((M, N), dtype=torch.float32, device=dev)
+        states = torch.empty((2 * S, M, N, D), dtype=torch.float32, device=dev)
+        folds = torch.empty((2 * S, Mp, 2, D), dtype=torch.float32, device=dev)
+        mean = torch.empty((2 * S, D), dtype=torch.float32, device=dev)
+        alpha = torch.empty((2 * S, D), dtype=torch.float32, device=dev)
+        nbytes = check(lib.tnf_flow_forward_train_workspace_bytes(M, Mp, N, D, S, L))
+        ws = _workspace(nbytes, dev)
+        check(lib.tnf_flow_forward_train_fwd_f32(oc.data_ptr(), pc.data_ptr(), z.data_ptr(), sld.data_ptr(),
+                                                 states.data_ptr(), folds.data_ptr(), mean.data_ptr(), alpha.data_ptr(),
+                                                 M, Mp, N, D, S, L, U, pstride, float(eps), ws.data_ptr(), nbytes,
+                                                 _lib.stream_ptr()))
+        ctx.save_for_backward(oc, pc, states, folds, mean, alpha)
+        ctx.cfg = (D, S, L, U, pstride, omega.device, params.device, tuple(params.shape))
+        ctx.mark_non_differentiable(mean, alpha)
+        return z, sld, mean, alpha
+
+    @staticmethod
+    def backward(ctx, g_z, g_sld, _gm, _ga):
+        oc, pc, states, folds, mean, alpha = ctx.saved_tensors
+        D, S, L, U, pstride, o_home, p_home, p_shape = ctx.cfg
+        dev = oc.device
+        M, N = oc.shape[0], oc.shape[1]
+        Mp = pc.shape[0]
+        gz = _stage(_grad_or_zeros(g_z, oc.shape, torch.float32, dev).float(), dev)
+        gs = _stage(_grad_or_zeros(g_sld, (M, N), torch.float32, dev).float(), dev)
+        go = torch.empty_like(oc) if ctx.needs_input_grad[0] else None
+        gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+        nbytes = check(lib.tnf_flow_forward_train_workspace_bytes(M, Mp, N, D, S, L))
+        ws = _workspace(nbytes, dev)
+        check(lib.tnf_flow_forward_train_bwd_f32(oc.data_ptr(), pc.data_ptr(), states.data_ptr(), folds.data_ptr(),
+                                                 mean.data_ptr(), alpha.data_ptr(), gz.data_ptr(), gs.data_ptr(),
+                                                 go.data_ptr() if go is not None else None, gp.data_ptr(), M, Mp, N, D, S,
+                                                 L, U, pstride, gp.shape[1], ws.data_ptr(), nbytes, _lib.stream_ptr()))
+        if go is not None and o_home != dev:
+            go = go.to(o_home)
+        return go, (gp if p_home == dev else gp.to(p_home)), None, None, None, None, None
+
+
+def flow_forward_train(omega, params, D, S, L, U, eps):
+    return _FlowForwardTrainFn.apply(omega, params, D, S, L, U, eps)
+
+
 def flow_train_supported(M, Mp, N, D, S, L, U):
     return Mp in (1, M) and N >= 32 and lib.tnf_flow_train_workspace_bytes(M, Mp, max(N, 1), D, S, L, U) >= 0
 
