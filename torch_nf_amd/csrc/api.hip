@@ -348,7 +348,7 @@ int tnf_ar_flow_train_supported(int32_t D, int32_t L, int32_t U) {
 
 int64_t tnf_ar_flow_bwd_workspace_bytes(int64_t M_p, int32_t D) {
     if (M_p < 1 || D < 1) return fail(TNF_EINVAL, "tnf_ar_flow_bwd_workspace_bytes: M_p=%lld D=%d", (long long)M_p, D);
-    return round16(M_p * (4 * (int64_t)D + 2) * (int64_t)sizeof(float));
+    return round16((M_p * (4 * (int64_t)D + 2) + 1) * (int64_t)sizeof(float));
 }
 
 int tnf_ar_flow_log_prob_bwd_f32(const float* z, const float* params, const float* masks, const float* bn_mean,

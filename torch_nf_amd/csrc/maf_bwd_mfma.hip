@@ -126,6 +126,11 @@ struct MafBwdArgs {
     const float* g_lp;
     float* g_fold;
     float* glp_sum;
+    // fused mode with one shared accumulator copy (nacc = 1): 32-bit fixed-point accumulators and ds_add_u32 instead of
+    // ds_add_f32 (44 x cheaper, tools/lds_atomic_bench.hip); g_lp is pre-scaled by the power of two that brings
+    // max |g_lp| (gmax, float bits) into [1, 2) and fx = 2^f leaves 2^13 per accumulated term inside int32.
+    const unsigned* gmax;
+    float fx;
 };
 
 constexpr int kMafLMax = 3;
@@ -155,6 +160,19 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     for (int i = threadIdx.x; i < nacc * NWG * 256; i += 256) gacc[i] = 0.f;
     const bool fusedm = a.g_lp != nullptr;
     const bool has_iv = a.iv != nullptr;
+    const bool fixedp = fusedm && a.gmax != nullptr;
+    float sc = 1.f, isc = 1.f, amax = 0.f;
+    if (fixedp) {
+        const float gm = __uint_as_float(*a.gmax);
+        if (gm > 0.f && gm < 3.0e38f) {
+            int e;
+            (void)frexpf(gm, &e);
+            int k = 1 - e;
+            k = k > 120 ? 120 : (k < -120 ? -120 : k);
+            sc = ldexpf(1.f, k);
+            isc = ldexpf(1.f, -k);
+        }
+    }
     if (fusedm) {
         for (int i = threadIdx.x; i < 2 * D; i += 256) cst[i] = a.pre[mp * 2 * D + i];
         if (has_iv)
@@ -176,6 +194,16 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
         if (nacc > 1) {
             f4* p = reinterpret_cast<f4*>(gdst + g * 256);
             *p = *p + v;
+        } else if (fixedp) {
+            int* p = reinterpret_cast<int*>(gdst + g * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = v[j] * a.fx;  // a plain VALU result: safe to read from inline asm (flow_bwd_f16.hip)
+                amax = fmaxf(amax, fabsf(t));
+                int r;
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(t));
+                atomicAdd(p + j, r);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) atomicAdd(gdst + g * 256 + j, v[j]);  // ds_add_f32
@@ -229,7 +257,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                 }
             }
         }
-        const float glv = row_ok ? glb[rr] : 0.f;
+        const float glv = row_ok ? sc * glb[rr] : 0.f;
         const float gl = fusedm ? -glv : glv;  // log_prob = base - (sum of forward log-dets)
         if (fusedm && q == 0) glp_acc += glv;
         asm volatile("" ::: "memory");
@@ -400,7 +428,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                     fdA[mm][j] = __builtin_fmaf(g[mm][j], xpre[mm][j], fdA[mm][j]);
                     fdB[mm][j] += g[mm][j];
                     const int f = 16 * mm + 4 * q + j;
-                    if (gzb && f < D) g[mm][j] *= cst[f];  // g wrt the MAF input -> wrt the fold's input (no ToInterval here)
+                    if (gzb && f < D) g[mm][j] *= cst[f] * isc;  // g wrt the MAF input -> wrt the fold's input (no ToInterval here)
                 }
         }
         if (row_ok && gzb) {
@@ -424,7 +452,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
         for (int mm = 0; mm < DT; ++mm)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float va = fdA[mm][j], vb = fdB[mm][j];
+                float va = fdA[mm][j] * isc, vb = fdB[mm][j] * isc;
                 for (int off = 8; off > 0; off >>= 1) {
                     va += __shfl_xor(va, off);
                     vb += __shfl_xor(vb, off);
@@ -436,7 +464,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                 }
             }
         for (int off = 8; off > 0; off >>= 1) glp_acc += __shfl_xor(glp_acc, off);
-        if (lane == 0) atomicAdd(red + 2 * D, glp_acc);
+        if (lane == 0) atomicAdd(red + 2 * D, glp_acc * isc);
         __syncthreads();
         const bool own_row = a.Mp > 1 && gridDim.x == 1;
         for (int i = threadIdx.x; i < 2 * D; i += 256) {
@@ -452,6 +480,17 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
     // ---- flush: tile (out tile ot, in tile it) element (o = 16 ot + 4q + j, k = 16 it + (lane & 15)) ----
     {
         const bool own = a.Mp > 1 && gridDim.x == 1;
+        float poison = 0.f, unfx = 1.f;
+        if (fixedp) {  // a term beyond the budget may have wrapped an accumulator: poison instead of returning it
+            for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+            float* pr = scr_all;
+            if (lane == 0) pr[wave] = amax;
+            __syncthreads();
+            amax = fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3]));
+            const float adds = (float)((ntiles + gridDim.x - 1) / gridDim.x);
+            if (amax * adds >= 2147483648.f) poison = __builtin_nanf("");
+            unfx = isc / a.fx;
+        }
         float* gp = a.g_params + mp * a.gpstride;
         const float* mk = a.masks;
         int64_t off = 0, moff = 0;
@@ -464,6 +503,10 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                 const int gidx = layer == 0 ? wl.g0(net, ot, it) : (layer == L ? wl.g2(net, ot, it) : wl.gh(layer - 1, net, ot, it));
                 f4 v = *reinterpret_cast<const f4*>(gacc + (gidx * 64 + lane) * 4);
                 for (int c = 1; c < nacc; ++c) v += *reinterpret_cast<const f4*>(gacc + c * NWG * 256 + (gidx * 64 + lane) * 4);
+                if (fixedp) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (float)__float_as_int(v[j]) * unfx + poison;
+                }
                 const int k = 16 * it + s;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -527,9 +570,25 @@ static int launch_maf_bwd_d(const MafBwdArgs& a, const MafBLayout& wl, dim3 grid
     }
 }
 
+static int maf_bwd_nacc(int D, int L, int U) { return maf_bwd_smem(maf_blayout(D, L, U), 4) <= 156 * 1024 ? 4 : 1; }
+
+__global__ void __launch_bounds__(256)
+maf_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
+}
+
 static int launch_maf_bwd_args(MafBwdArgs& a, hipStream_t st) {
     const MafBLayout wl = maf_blayout(a.D, a.L, a.U);
-    const int nacc = maf_bwd_smem(wl, 4) <= 156 * 1024 ? 4 : 1;
+    const int nacc = maf_bwd_nacc(a.D, a.L, a.U);
     const size_t smem = maf_bwd_smem(wl, nacc);
     a.nacc = nacc;
     const int64_t ntiles = (a.N + 15) / 16;
@@ -586,12 +645,29 @@ int launch_ar_flow_backward(const float* z, const float* params, const float* ma
     if (!maf_bwd_mfma_supported(D, L, U))
         return fail(TNF_EUNSUPPORTED, "ar_flow_backward: no kernel for D=%d L=%d U=%d", D, L, U);
     if (N <= 0) return TNF_OK;
-    if (hipMemsetAsync(g_fold, 0, (size_t)(Mp * 2 * D + Mp) * sizeof(float), st) != hipSuccess)
+    if (hipMemsetAsync(g_fold, 0, (size_t)(Mp * 2 * D + Mp + 1) * sizeof(float), st) != hipSuccess)
         return fail(TNF_ELAUNCH, "ar_flow_backward: memset failed");
     MafBwdArgs a = {};
     a.z = z; a.params = params; a.masks = masks; a.g_params = g_params;
     a.M = M; a.Mp = Mp; a.N = N; a.pstride = pstride; a.gpstride = gpstride; a.D = D; a.L = L; a.U = U;
     a.pre = fold; a.iv = interval_consts; a.g_lp = g_lp; a.g_fold = g_fold; a.glp_sum = glp_sum;
+    if (maf_bwd_nacc(D, L, U) == 1) {  // shared accumulators: fixed point, scaled by the largest upstream gradient
+        unsigned* gmax = reinterpret_cast<unsigned*>(glp_sum + Mp);
+        const int64_t n = M * N;
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 256) blocks = 256;
+        hipLaunchKernelGGL(maf_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_lp, n, gmax);
+        const int64_t ntiles = (N + 15) / 16;
+        int64_t bx = (ntiles + 3) / 4;
+        if (Mp > 1) bx = 1;
+        else if (bx > 512) bx = 512;
+        const int64_t adds = (ntiles + bx - 1) / bx;  // tiles (= terms per accumulator) per workgroup
+        int fbits = 31 - 13;
+        for (int64_t v = 1; v < adds; v <<= 1) --fbits;
+        if (fbits < 0) fbits = 0;
+        a.gmax = gmax;
+        a.fx = ldexpf(1.f, fbits);
+    }
     int rc = launch_maf_bwd_args(a, st);
     if (rc != TNF_OK) return rc;
     const int64_t p_maf = 2 * ((int64_t)D * U + (int64_t)(L - 1) * U * U + (int64_t)U * D) + 0;
