@@ -550,54 +550,59 @@ int launch_flow_forward_batch(const float* omega, const float* params, float* z_
 //   g_r = sum_m e (P - mu Q) + (sum_m S_m)/r,  g_mu = -r sum_m e Q      (sum_log_det carries -log alpha = log r)
 //   g_v = g_x r e + k0 + k1 v,  k1 = -g_r r^3 / R,  k0 = g_mu / R - k1 mu
 // ---------------------------------------------------------------------------
-// per-context sums over the samples: PQ[mp] += [sum g v (D) | sum g (D)];  S[mp] += sum g_sld (when sld given)
+// per-context sums over the samples: PQ[mp] += [sum g v (D) | sum g (D)];  S[mp] += sum g_sld (when sld given).
+// D % 4 == 0: 16-byte loads, D/4 lanes per row, four rows in flight per lane.
 __global__ void __launch_bounds__(256)
 fold_sums_kernel(const float* __restrict__ g, const float* __restrict__ v, const float* __restrict__ g_sld,
                  float* __restrict__ PQ, float* __restrict__ Ssum, int64_t Mp, int64_t N, int D, int64_t rows_per_block) {
-    __shared__ float red[256 * 2];
+    extern __shared__ float fsred[];  // [rpi][2][D]
     const int64_t m = grid_m();
     const int64_t mp = Mp == 1 ? 0 : m;
     const int tid = threadIdx.x;
-    const int rpi = 256 / D > 0 ? 256 / D : 1;
+    const int lanes = D >> 2, rpi = 256 / lanes;
+    const int r = tid / lanes, q = tid - r * lanes;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > N) r1 = N;
-    for (int dc = 0; dc < D; dc += 256) {
-        const int Dc = (D - dc) < 256 ? (D - dc) : 256;
-        const int rp = 256 / Dc;
-        const int r = tid / Dc, d = tid - r * Dc;
-        float p = 0.f, q = 0.f;
-        if (r < rp)
-            for (int64_t row = r0 + r; row < r1; row += rp) {
-                const float gv = g[(m * N + row) * D + dc + d];
-                p = fmaf(gv, v[(m * N + row) * D + dc + d], p);
-                q += gv;
+    const float* gb = g + m * N * D;
+    const float* vb = v + m * N * D;
+    f4 p = {0.f, 0.f, 0.f, 0.f}, s = {0.f, 0.f, 0.f, 0.f};
+    if (r < rpi) {
+        for (int64_t row = r0 + r; row < r1; row += 4 * (int64_t)rpi) {
+            f4 gv[4], vv[4];  // eight 16-byte loads in flight per lane
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rw = row + u * (int64_t)rpi;
+                const bool ok = rw < r1;
+                gv[u] = ok ? *reinterpret_cast<const f4*>(gb + rw * D + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+                vv[u] = ok ? *reinterpret_cast<const f4*>(vb + rw * D + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
             }
-        red[tid] = p;
-        red[256 + tid] = q;
-        __syncthreads();
-        if (tid < Dc) {
-            float a = 0.f, b = 0.f;
-            for (int rr = 0; rr < rp; ++rr) {
-                a += red[rr * Dc + tid];
-                b += red[256 + rr * Dc + tid];
-            }
-            atomicAdd(PQ + mp * 2 * D + dc + tid, a);
-            atomicAdd(PQ + mp * 2 * D + D + dc + tid, b);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    p[j] = __builtin_fmaf(gv[u][j], vv[u][j], p[j]);
+                    s[j] += gv[u][j];
+                }
         }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fsred[(r * 2 + 0) * D + 4 * q + j] = p[j];
+            fsred[(r * 2 + 1) * D + 4 * q + j] = s[j];
+        }
     }
-    (void)rpi;
+    __syncthreads();
+    for (int d = tid; d < 2 * D; d += 256) {
+        float a = 0.f;
+        for (int rr = 0; rr < rpi; ++rr) a += fsred[rr * 2 * D + d];
+        atomicAdd(PQ + mp * 2 * D + d, a);
+    }
     if (g_sld) {
+        __syncthreads();
         float sacc = 0.f;
         for (int64_t row = r0 + tid; row < r1; row += 256) sacc += g_sld[m * N + row];
-        red[tid] = sacc;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) red[tid] += red[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) atomicAdd(Ssum + mp, red[0]);
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+        if ((tid & 63) == 0) atomicAdd(Ssum + mp, sacc);
     }
 }
 
@@ -640,10 +645,10 @@ fold_bwd_apply_kernel(const float* g_in, const float* __restrict__ v, const floa
     const float* A = fold ? fold + mp * 2 * D : nullptr;
     const int64_t total = N * D, base = m * N * D;
     const int64_t step = (int64_t)gridDim.x * 1024;
-    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += 2 * step) {
-        f4 gv[2], vv[2];
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < total; i0 += 4 * step) {
+        f4 gv[4], vv[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int64_t i = i0 + u * step;
             if (i < total) {
                 gv[u] = *reinterpret_cast<const f4*>(g_in + base + i);
@@ -651,7 +656,7 @@ fold_bwd_apply_kernel(const float* g_in, const float* __restrict__ v, const floa
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int64_t i = i0 + u * step;
             if (i < total) {
                 const int d = (int)(i % D);
@@ -740,15 +745,19 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
     if (rc) return rc;
     int64_t nb = (N * D / 4 + 255) / 256;
     if (nb > 2048) nb = 2048;
-    int64_t sb = (N + 255) / 256;
-    if (sb > 256) sb = 256;
+    const int fs_rpi = 256 / (D / 4);
+    int64_t sb = (N + 4 * fs_rpi - 1) / (4 * fs_rpi);
+    const int64_t sb_cap = (512 + M - 1) / M;  // few workgroups: their atomics land on the same 2 D words per context
+    if (sb > sb_cap) sb = sb_cap;
+    if (sb < 1) sb = 1;
     const int64_t rpb = (N + sb - 1) / sb;
     const double rows = (double)M * (double)N;
     // ---- the last fold (behind layer nl-1): sums over (g_z, v), then g_v ----
     if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D + Mp) * sizeof(float), st) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_forward_train_bwd: memset failed");
     const float* v_last = states + (int64_t)(nl - 1) * plane;
-    hipLaunchKernelGGL(fold_sums_kernel, grid_xm(sb, M), dim3(256), 0, st, g_z, v_last, g_sld, PQ, Ssum, Mp, N, D, rpb);
+    hipLaunchKernelGGL(fold_sums_kernel, grid_xm(sb, M), dim3(256), (size_t)fs_rpi * 2 * D * sizeof(float), st, g_z, v_last,
+                       g_sld, PQ, Ssum, Mp, N, D, rpb);
     int cur = 0;
     for (int c = nl - 1; c >= 0; --c) {
         // fold behind layer c: PQ holds its sums (from fold_sums for the last one, else from the layer c+1 backward)

@@ -310,15 +310,15 @@ bn_stats_vec_kernel(const float* __restrict__ z, double* __restrict__ sums, int6
         int64_t row = r0 + r;
         while (row < r1) {
             float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < 16 && row < r1; ++k, row += 4 * (int64_t)rpi) {
-                float4 v[4];  // four rows in flight per lane
+            for (int k = 0; k < 8 && row < r1; ++k, row += 8 * (int64_t)rpi) {
+                float4 v[8];  // eight rows in flight per lane
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int64_t rw = row + u * (int64_t)rpi;
                     v[u] = rw < r1 ? *reinterpret_cast<const float4*>(z + rw * D + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     a1[0] += v[u].x; a1[1] += v[u].y; a1[2] += v[u].z; a1[3] += v[u].w;
                     a2[0] = fmaf(v[u].x, v[u].x, a2[0]); a2[1] = fmaf(v[u].y, v[u].y, a2[1]);
                     a2[2] = fmaf(v[u].z, v[u].z, a2[2]); a2[3] = fmaf(v[u].w, v[u].w, a2[3]);
@@ -383,6 +383,12 @@ static void launch_bn_sums(const float* z, double* sums, int64_t rows, int D, in
     const bool vec = (D % 4) == 0 && D <= 1024 && (reinterpret_cast<uintptr_t>(z) & 15) == 0;
     if (vec) {
         const int rpi = 256 / (D / 4);
+        // a streaming read: eight 16-byte loads per lane in flight, and few enough workgroups (two per CU) that
+        // their 2 D double atomics per workgroup do not queue up on the 2 D result words (4096 workgroups: 126 us)
+        blocks = (rows + 8 * rpi - 1) / (8 * rpi);
+        if (blocks > 512) blocks = 512;
+        if (blocks < 1) blocks = 1;
+        rpb = (rows + blocks - 1) / blocks;
         hipLaunchKernelGGL(bn_stats_vec_kernel, dim3((unsigned)blocks), dim3(256), (size_t)rpi * 2 * D * sizeof(double), st, z,
                            sums, rows, D, rpb);
     } else {
