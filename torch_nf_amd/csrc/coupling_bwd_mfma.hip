@@ -125,7 +125,7 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
     typedef LdsLayerImage<H, L> FImg;
     typedef BwdImage<H, L> BImg;
     constexpr int SCR = 17 * 16;  // one padded 16x16 tile
-    __shared__ __attribute__((aligned(16))) float lds[FImg::FLOATS + BImg::FLOATS + 4 * 2 * SCR + 2 * D];
+    __shared__ __attribute__((aligned(16))) float lds[FImg::FLOATS + BImg::FLOATS + 4 * 2 * SCR + 4 * D];
     float* fimg = lds;
     float* bimg = lds + FImg::FLOATS;
     float* cf = lds + FImg::FLOATS + BImg::FLOATS + 4 * 2 * SCR;  // fold constants A | B
@@ -153,6 +153,9 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
     }
     if (wave == 1) build_bwd_image<H, L>(bimg, prow, a.U, lane);
     for (int i = threadIdx.x; i < 2 * D; i += 256) cf[i] = has_fold ? a.fold[mp * a.fold_stride + i] : (i < D ? 1.f : 0.f);
+    const bool has_corr = !INV && a.gcorr != nullptr;
+    if (has_corr)
+        for (int i = threadIdx.x; i < 2 * D; i += 256) cf[2 * D + i] = a.gcorr[i];
     __syncthreads();
     const LdsOperands<H, L> fop(fimg, lane);
     const float* bl = bimg + lane * 4;
@@ -217,6 +220,11 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
                 for (int j = 0; j < 4; ++j) gx[mm][j] = -glp * x[mm][j];
                 gy[mm] = zero;  // needs the transformed output: filled in below
             }
+            if (has_corr) {  // the conditioner half of the output is x itself
+                const f4 k0 = *reinterpret_cast<const f4*>(cfx + 2 * D + 16 * mm), k1 = *reinterpret_cast<const f4*>(cfx + 3 * D + 16 * mm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gx[mm][j] += __builtin_fmaf(k1[j], x[mm][j], k0[j]);
+            }
             if (!row_ok) { gx[mm] = zero; gy[mm] = zero; }  // padded rows contribute nothing
         }
         const float gl = row_ok ? a.ld_scale * gld[rowc] : 0.f;
@@ -273,6 +281,8 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
                     dout[1][mo][j] = __builtin_fmaf(-g, yo, gl);
                 } else {    // y' = t + y e^s
                     const float e = __builtin_amdgcn_exp2f(sv[j]);
+                    if (has_corr && row_ok)
+                        g += __builtin_fmaf(cfy[3 * D + 16 * mo + j], __builtin_fmaf(y[mo][j], e, tt[j]), cfy[2 * D + 16 * mo + j]);
                     dy[j] = g * e;
                     dout[0][mo][j] = g;
                     dout[1][mo][j] = __builtin_fmaf(g * y[mo][j], e, gl);
@@ -503,7 +513,7 @@ int launch_coupling_backward_mfma(const float* z, const float* params, const flo
                                   int64_t gpstride, hipStream_t st) {
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "coupling_backward_mfma: D=%d L=%d U=%d", D, L, U);
     BwdArgs a{z, params, g_zout, g_ld, g_z, g_params, M, Mp, N, pstride, gpstride, U, upper,
-              nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, nullptr};
+              nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, nullptr, nullptr};
     return launch_coupling_backward_mfma_args(a, D, L, inverse, st);
 }
 

@@ -765,10 +765,14 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
         const int64_t aff = (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low;
         hipLaunchKernelGGL(fold_backward_kernel, dim3(1), dim3(256), 0, st, params, pstride, aff, bn_mean + (int64_t)c * D,
                            bn_alpha + (int64_t)c * D, PQ, Ssum, g_params, gpstride, kk, Mp, rows, D, c & 1);
-        // g wrt v_c: the last fold still has to apply A; the inner ones got it from the coupling backward already
-        hipLaunchKernelGGL(fold_bwd_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, g_in, states + (int64_t)c * plane,
-                           (c == nl - 1) ? folds + (int64_t)c * Mp * 2 * D : nullptr, kk, gbuf[cur ^ 1], Mp, N, D);
-        cur ^= 1;
+        // g wrt v_c = g_x A + k0 + k1 v_c.  The last fold applies it in a pass of its own (A included); for the inner
+        // ones the coupling backward of the layer behind already multiplied by A, and k0 + k1 v_c is added by the
+        // coupling backward kernel of layer c itself in its load stage (v_c is that layer's output).
+        if (c == nl - 1) {
+            hipLaunchKernelGGL(fold_bwd_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, g_in, states + (int64_t)c * plane,
+                               folds + (int64_t)c * Mp * 2 * D, kk, gbuf[cur ^ 1], Mp, N, D);
+            cur ^= 1;
+        }
         // coupling layer c
         if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D) * sizeof(float), st) != hipSuccess)
             return fail(TNF_ELAUNCH, "flow_forward_train_bwd: memset failed");
@@ -790,6 +794,7 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
         a.fold = c == 0 ? nullptr : folds + (int64_t)(c - 1) * Mp * 2 * D;
         a.g_fold = c == 0 ? nullptr : PQ;
         a.fold_stride = 2 * (int64_t)D;
+        a.gcorr = (c == nl - 1) ? nullptr : kk;
         rc = launch_coupling_backward_mfma_args(a, D, L, 0, st);
         if (rc) return rc;
         cur ^= 1;

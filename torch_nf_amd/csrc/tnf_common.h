@@ -182,6 +182,8 @@ struct BwdArgs {
     const float* g_lp;    // finalize: upstream gradient is that of log_prob = -|out|^2/2 - ... (M,N)
     float ld_scale;       // gradient w.r.t. sum(s) = ld_scale * g_ld[row]
     float* glp_sum;       // finalize: accumulates sum over the samples of g_lp (per mp), for the constant log-det
+    const float* gcorr;   // [k0 (D) | k1 (D)] or NULL: the upstream gradient is g_zout + k0 + k1 * (this layer's output)
+                          // (batch-statistics backward of the fold behind the layer, forward direction only)
 };
 int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);
 int launch_coupling_backward_mfma(const float* z, const float* params, const float* g_zout,
