@@ -139,6 +139,46 @@ def widened_rows(tnf):
     res["ar_log_prob"] = {"samples": 1 << 20, "ms": round(t * 1e3, 3), "value": round((1 << 20) / t / 1e6, 1),
                           "unit": "M samples/s", "what": "NormFlow(16, arch_type='AR', num_layers=2, num_units=32).log_prob, "
                           "one matrix-pipe MAF kernel"}
+    del z, nf
+    # the LFI scripts' inner step (scripts/lfi_mat.py:23-57): AR flow + ToInterval through param_net [64,64]
+    D_l, M_l, N_l = 6, 2000, 100
+    lb, ub = -2.0 * np.ones(D_l), 2.0 * np.ones(D_l)
+    lb[::2] = -np.inf
+    nfl = tnf.NormFlow(D_l, True, "AR", 1, 2, 2 * D_l, tnf.ToInterval(D_l, lb, ub))
+    cdel = tnf.ConditionalDensityEstimator(nfl, 3, [64, 64])
+    xl = torch.randn(M_l, 3, device="cuda")
+    zl = torch.rand(M_l, N_l, D_l, device="cuda") * 3.0 - 1.5
+    optl = torch.optim.Adam(cdel.parameters(), lr=1e-3, capturable=True)
+
+    def lfi_step():
+        optl.zero_grad(set_to_none=True)
+        loss = -cdel.log_prob(zl, xl).mean()
+        loss.backward()
+        optl.step()
+        return loss.detach()
+
+    te = timeit(lfi_step, 10)
+    gs = tnf.graphs.GraphedStep(lfi_step, warmup=3)
+    tg = timeit(gs, 20)
+    res["lfi_train_step"] = {"samples": M_l * N_l, "ms": round(tg * 1e3, 3), "eager_ms": round(te * 1e3, 3),
+                             "value": round(M_l * N_l / tg / 1e6, 1), "unit": "M samples/s",
+                             "what": "AR flow (D=6) + ToInterval conditioned through param_net [64,64], 2000 contexts x 100 "
+                             "samples: loss, one-kernel AR backward, Adam; replayed as one HIP graph (eager_ms: eagerly)"}
+    del cdel, nfl, xl, zl, optl, gs
+    # sampling with fresh batch statistics under autograd (the reference's train_efn objective shape)
+    nfe = tnf.NormFlow(64, False, "coupling", 4, 2, 15)
+    nfe.params = (torch.randn(1, nfe.D_params, device="cuda") * 0.1).requires_grad_()
+    om = torch.randn(1, 1 << 19, 64, device="cuda")
+
+    def efn():
+        nfe.params.grad = None
+        ze, lqe = nfe._forward_from(om, nfe.params, freeze_bn=False)
+        (lqe.mean() + (ze ** 2).mean()).backward()
+
+    t = timeit(efn, 5)
+    res["forward_train_step"] = {"samples": 1 << 19, "ms": round(t * 1e3, 3), "value": round((1 << 19) / t / 1e6, 1),
+                                 "unit": "M samples/s", "what": "z, log_q = nf(N) with fresh batch statistics, D=64 S=4; "
+                                 "backward through the batch moments (one autograd node, tnf_flow_forward_train_*)"}
     return res
 
 
