@@ -14,7 +14,7 @@
 //      accumulate dW in registers across all tiles a wave processes.
 // Bias gradients are per-lane partial sums reduced across the 16 sample lanes at the end.
 // Each wave finally adds its dW / db to the parameter-gradient row with float atomics
-// (one atomic per parameter per wave; order-dependent in the last bits).
+// (waves in turn, plain LDS read-add-writes; then one global atomic per parameter per workgroup).
 //
 // tanh'(a) = 1 - h^2 = 4 r (1 - r) with r the folded sigmoid the forward pass produces.
 #include "mfma_tile.h"
@@ -95,6 +95,8 @@ __device__ __forceinline__ void build_bwd_image(float* img, const float* __restr
         }
     }
 }
+
+__device__ __forceinline__ void lds_plus(float* p, float v) { *p += v; }
 
 // acc layout (lane (s,q), reg j = row 4q+j, col s)  ->  operand layout with K = samples
 // (lane (c = lane&15, kq = lane>>4), reg i = element [row c][sample 4i + kq]).
@@ -396,101 +398,109 @@ coupling_bwd_mfma_kernel(BwdArgs a) {
     const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
     for (int i = threadIdx.x; i < P + 2 * D; i += 256) gacc[i] = 0.f;
     __syncthreads();
-    const int c = lane & 15;  // column of the dW accumulators; rows are 4q + j
-    auto red16 = [&](float v) -> float {  // sum over the 16 sample lanes of a q-group
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8);
-        return v;
-    };
-    float* gp = gacc;
-    {   // layer 0
-        float* gwt = gp;
-        float* gws = gp + H * U;
-        float* gbt = gp + 2 * H * U;
-        float* gbs = gbt + U;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int u = 4 * q + j;
-#pragma unroll
-            for (int mm = 0; mm < HT; ++mm) {
-                const int f = 16 * mm + c;
-                if (u < U && f < H) {
-                    atomicAdd(gwt + f * U + u, dW0[0][mm][j]);
-                    atomicAdd(gws + f * U + u, dW0[1][mm][j]);
+    // The four waves add their register accumulators in turn with plain read-add-writes: within a wave every lane
+    // owns its element, and ds_add_f32 costs ~190 cycles per wave-instruction on gfx950 (tools/lds_atomic_bench.hip;
+    // 84 of them per wave made this tail tens of microseconds long).
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+            const int c = lane & 15;  // column of the dW accumulators; rows are 4q + j
+            auto red16 = [&](float v) -> float {  // sum over the 16 sample lanes of a q-group
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                return v;
+            };
+            float* gp = gacc;
+            {   // layer 0
+                float* gwt = gp;
+                float* gws = gp + H * U;
+                float* gbt = gp + 2 * H * U;
+                float* gbs = gbt + U;
+        #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = 4 * q + j;
+        #pragma unroll
+                    for (int mm = 0; mm < HT; ++mm) {
+                        const int f = 16 * mm + c;
+                        if (u < U && f < H) {
+                            lds_plus(gwt + f * U + u, dW0[0][mm][j]);
+                            lds_plus(gws + f * U + u, dW0[1][mm][j]);
+                        }
+                    }
+                    const float bt = red16(db0[0][j]), bs = red16(db0[1][j]);
+                    if (s == 0 && u < U) {
+                        lds_plus(gbt + u, bt);
+                        lds_plus(gbs + u, bs);
+                    }
                 }
+                gp = gbs + U;
             }
-            const float bt = red16(db0[0][j]), bs = red16(db0[1][j]);
-            if (s == 0 && u < U) {
-                atomicAdd(gbt + u, bt);
-                atomicAdd(gbs + u, bs);
+        #pragma unroll
+            for (int l = 0; l < L - 1; ++l) {
+                float* gwt = gp;
+                float* gws = gp + U * U;
+                float* gbt = gp + 2 * U * U;
+                float* gbs = gbt + U;
+        #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ko = 4 * q + j, ki = c;
+                    if (ko < U && ki < U) {
+                        lds_plus(gwt + ki * U + ko, dWh[l][0][j]);
+                        lds_plus(gws + ki * U + ko, dWh[l][1][j]);
+                    }
+                    const float bt = red16(dbh[l][0][j]), bs = red16(dbh[l][1][j]);
+                    if (s == 0 && ko < U) {
+                        lds_plus(gbt + ko, bt);
+                        lds_plus(gbs + ko, bs);
+                    }
+                }
+                gp = gbs + U;
+            }
+            {
+                float* gwt = gp;
+                float* gws = gp + U * H;
+                float* gbt = gp + 2 * U * H;
+                float* gbs = gbt + H;
+        #pragma unroll
+                for (int mo = 0; mo < HT; ++mo)
+        #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int o = 16 * mo + 4 * q + j, k = c;
+                        if (k < U && o < H) {
+                            lds_plus(gwt + k * H + o, dW2[0][mo][j]);
+                            lds_plus(gws + k * H + o, dW2[1][mo][j]);
+                        }
+                        const float bt = red16(db2[0][mo][j]), bs = red16(db2[1][mo][j]);
+                        if (s == 0 && o < H) {
+                            lds_plus(gbt + o, bt);
+                            lds_plus(gbs + o, bs);
+                        }
+                    }
+            }
+            if (finalize && a.glp_sum) {
+                const float tot = red16(glp_acc);
+                if (lane == 0) atomicAdd(a.glp_sum + mp, tot);
+            }
+            if (a.g_fold) {  // fold-constant gradients: reduce over the 16 sample lanes, then LDS
+                float* gf = gacc + P;  // [dA (D) | dB (D)], zeroed with the rest below P? no: zero it here first
+        #pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+        #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ax = red16(dAx[mm][j]), bx = red16(dBx[mm][j]);
+                        const float ay = red16(dAy[mm][j]), by = red16(dBy[mm][j]);
+                        if (s == 0) {
+                            const int fx = c_off + 16 * mm + 4 * q + j, fy = t_off + 16 * mm + 4 * q + j;
+                            lds_plus(gf + fx, ax);
+                            lds_plus(gf + D + fx, bx);
+                            lds_plus(gf + fy, ay);
+                            lds_plus(gf + D + fy, by);
+                        }
+                    }
             }
         }
-        gp = gbs + U;
-    }
-#pragma unroll
-    for (int l = 0; l < L - 1; ++l) {
-        float* gwt = gp;
-        float* gws = gp + U * U;
-        float* gbt = gp + 2 * U * U;
-        float* gbs = gbt + U;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ko = 4 * q + j, ki = c;
-            if (ko < U && ki < U) {
-                atomicAdd(gwt + ki * U + ko, dWh[l][0][j]);
-                atomicAdd(gws + ki * U + ko, dWh[l][1][j]);
-            }
-            const float bt = red16(dbh[l][0][j]), bs = red16(dbh[l][1][j]);
-            if (s == 0 && ko < U) {
-                atomicAdd(gbt + ko, bt);
-                atomicAdd(gbs + ko, bs);
-            }
-        }
-        gp = gbs + U;
-    }
-    {
-        float* gwt = gp;
-        float* gws = gp + U * H;
-        float* gbt = gp + 2 * U * H;
-        float* gbs = gbt + H;
-#pragma unroll
-        for (int mo = 0; mo < HT; ++mo)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int o = 16 * mo + 4 * q + j, k = c;
-                if (k < U && o < H) {
-                    atomicAdd(gwt + k * H + o, dW2[0][mo][j]);
-                    atomicAdd(gws + k * H + o, dW2[1][mo][j]);
-                }
-                const float bt = red16(db2[0][mo][j]), bs = red16(db2[1][mo][j]);
-                if (s == 0 && o < H) {
-                    atomicAdd(gbt + o, bt);
-                    atomicAdd(gbs + o, bs);
-                }
-            }
-    }
-    if (finalize && a.glp_sum) {
-        const float tot = red16(glp_acc);
-        if (lane == 0) atomicAdd(a.glp_sum + mp, tot);
-    }
-    if (a.g_fold) {  // fold-constant gradients: reduce over the 16 sample lanes, then LDS
-        float* gf = gacc + P;  // [dA (D) | dB (D)], zeroed with the rest below P? no: zero it here first
-#pragma unroll
-        for (int mm = 0; mm < HT; ++mm)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float ax = red16(dAx[mm][j]), bx = red16(dBx[mm][j]);
-                const float ay = red16(dAy[mm][j]), by = red16(dBy[mm][j]);
-                if (s == 0) {
-                    const int fx = c_off + 16 * mm + 4 * q + j, fy = t_off + 16 * mm + 4 * q + j;
-                    atomicAdd(gf + fx, ax);
-                    atomicAdd(gf + D + fx, bx);
-                    atomicAdd(gf + fy, ay);
-                    atomicAdd(gf + D + fy, by);
-                }
-            }
+        __syncthreads();
     }
     __syncthreads();
     float* gout = a.g_params + mp * a.gpstride;
