@@ -223,6 +223,16 @@ __device__ __forceinline__ f4 outer16h(const T16& a, const T16& b) {
     acc = mfma16h(a.lo, b.hi, acc);
     return mfma16h(a.hi, b.lo, acc);
 }
+__device__ __forceinline__ f4 outer16h_acc(const T16& a, const T16& b, f4 acc) {
+    acc = mfma16h(a.hi, b.hi, acc);
+    acc = mfma16h(a.lo, b.hi, acc);
+    return mfma16h(a.hi, b.lo, acc);
+}
+__device__ __forceinline__ f4 rowsum16h_acc(const T16& a, f4 acc) {
+    const h4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    acc = mfma16h(a.hi, ones, acc);
+    return mfma16h(a.lo, ones, acc);
+}
 __device__ __forceinline__ f4 rowsum16h(const T16& a) {
     const h4 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
     f4 acc = mfma16h(a.hi, ones, f4{0.f, 0.f, 0.f, 0.f});
@@ -305,12 +315,70 @@ struct FlowBwdArgs {
 // One coupling layer backwards on one tile.  x: conditioner half (= layer input and output);
 // y: in = transformed half of the OUTPUT, out = of the INPUT;  gx, gy: in = gradients wrt the layer's
 // outputs, out = wrt its inputs;  gl = d loss / d (sum of s) for this sample (natural log units).
+// Where a tile's weight-gradient contributions go.  LdsFxAccum: the whole-flow kernel (a wave meets every layer, so
+// the accumulators are shared fixed-point LDS words).  RegAccum: a kernel that stays on one layer keeps them in
+// registers and lets the MFMAs accumulate.
+template <int H, int L>
+struct LdsFxAccum {
+    typedef AccLayout<H, L> A_;
+    int* acc;
+    FxAcc& fa;
+    int s, q;
+    __device__ __forceinline__ void w2(int net, int mo, const T16& d_t, const T16& h_t) {
+        lds_add4(acc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mo + 4 * q, outer16h(d_t, h_t), fa);
+    }
+    __device__ __forceinline__ void b2(int net, int mo, const T16& d_t) {
+        lds_add_rows(acc + A_::o_b2 + net * H + 16 * mo + 4 * q, rowsum16h(d_t), s, fa);
+    }
+    __device__ __forceinline__ void wh(int l, int net, const T16& d_t, const T16& h_t) {
+        lds_add4(acc + A_::o_h + l * A_::HID + (net * 16 + s) * A_::US + 4 * q, outer16h(d_t, h_t), fa);
+    }
+    __device__ __forceinline__ void bh(int l, int net, const T16& d_t) {
+        lds_add_rows(acc + A_::o_h + l * A_::HID + 2 * 16 * A_::US + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
+    }
+    __device__ __forceinline__ void b0(int net, const T16& d_t) {
+        lds_add_rows(acc + A_::o_b0 + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
+    }
+    __device__ __forceinline__ void w0(int net, int mm, const T16& d_t, const T16& x_t) {
+        lds_add4(acc + A_::o_w0 + (net * H + 16 * mm + s) * A_::US + 4 * q, outer16h(d_t, x_t), fa);
+    }
+};
+
+template <int H, int L>
+struct RegAccum {
+    static constexpr int HT = (H + 15) / 16;
+    static constexpr int LH = (L > 1) ? (L - 1) : 1;
+    f4 W0[2][HT], Wh[LH][2], W2[2][HT], B0[2], Bh[LH][2], B2[2][HT];
+    __device__ __forceinline__ void clear() {
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            B0[net] = z;
+#pragma unroll
+            for (int t = 0; t < HT; ++t) W0[net][t] = W2[net][t] = B2[net][t] = z;
+#pragma unroll
+            for (int l = 0; l < LH; ++l) Wh[l][net] = Bh[l][net] = z;
+        }
+    }
+    __device__ __forceinline__ void w2(int net, int mo, const T16& d_t, const T16& h_t) { W2[net][mo] = outer16h_acc(d_t, h_t, W2[net][mo]); }
+    __device__ __forceinline__ void b2(int net, int mo, const T16& d_t) { B2[net][mo] = rowsum16h_acc(d_t, B2[net][mo]); }
+    __device__ __forceinline__ void wh(int l, int net, const T16& d_t, const T16& h_t) { Wh[l][net] = outer16h_acc(d_t, h_t, Wh[l][net]); }
+    __device__ __forceinline__ void bh(int l, int net, const T16& d_t) { Bh[l][net] = rowsum16h_acc(d_t, Bh[l][net]); }
+    __device__ __forceinline__ void b0(int net, const T16& d_t) { B0[net] = rowsum16h_acc(d_t, B0[net]); }
+    __device__ __forceinline__ void w0(int net, int mm, const T16& d_t, const T16& x_t) { W0[net][mm] = outer16h_acc(d_t, x_t, W0[net][mm]); }
+};
+
 // SPARE (num_units <= 15): hidden unit 15 is padding, so the transposed activation operand carries a row of
 // ones there and the bias gradients of the layers behind a tanh arrive as column 15 of the weight-gradient tiles.
-template <int H, int L, bool SPARE>
-__device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& fa, float* scrA, float* scrB, int lane, int U,
+// FWD = false: the inverse-pass layer of the whole-flow kernel (y comes in as the layer's OUTPUT and leaves as its
+// input).  FWD = true: a forward-direction layer y' = t + y e^s with its INPUT saved (y stays); kc, when not NULL,
+// points at this lane's [k0 | k1] constants (k1 at kc + D) of the batch-moment correction for the transformed
+// half: the upstream gradient is g + k0 + k1 y'.
+template <int H, int L, bool SPARE, bool FWD, class ACCP>
+__device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float* scrA, float* scrB, int lane, int U,
                                             const f4 (&x)[(H + 15) / 16], f4 (&y)[(H + 15) / 16],
-                                            f4 (&gx)[(H + 15) / 16], f4 (&gy)[(H + 15) / 16], float gl) {
+                                            f4 (&gx)[(H + 15) / 16], f4 (&gy)[(H + 15) / 16], float gl,
+                                            const float* kc = nullptr) {
     typedef F16Image<H, L> FImg;
     typedef B16Image<H, L> BImg;
     typedef RevImage<H, L> R;
@@ -326,7 +394,6 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         lo = __builtin_bit_cast(h4, u2{wv[2], wv[3]});
     };
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
-    typedef AccLayout<H, L> A_;
     h4 ident;  // B operand of the identity: lane (n = s, q) holds K = 4q + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) ident[i] = (4 * q + i == s) ? (_Float16)1.f : (_Float16)0.f;
@@ -401,13 +468,23 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
             // ---- 2. rebuild the input, output deltas ----
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float e = __builtin_amdgcn_exp2f(sv[j]), em = __builtin_amdgcn_exp2f(-sv[j]);
-                const float g = gy[mo][j], yo = y[mo][j];
-                const float dy = g * em;
-                dout[0][mo][j] = -dy;
-                dout[1][mo][j] = __builtin_fmaf(-g, yo, gl);
-                y[mo][j] = __builtin_fmaf(yo, e, tt[j]);
-                gy[mo][j] = dy;
+                const float e = __builtin_amdgcn_exp2f(sv[j]);
+                if (FWD) {
+                    float g = gy[mo][j];
+                    if (kc) g += __builtin_fmaf(kc[2 * H + 16 * mo + j], __builtin_fmaf(y[mo][j], e, tt[j]), kc[16 * mo + j]);
+                    const float dy = g * e;
+                    dout[0][mo][j] = g;
+                    dout[1][mo][j] = __builtin_fmaf(g * y[mo][j], e, gl);
+                    gy[mo][j] = dy;
+                } else {
+                    const float em = __builtin_amdgcn_exp2f(-sv[j]);
+                    const float g = gy[mo][j], yo = y[mo][j];
+                    const float dy = g * em;
+                    dout[0][mo][j] = -dy;
+                    dout[1][mo][j] = __builtin_fmaf(-g, yo, gl);
+                    y[mo][j] = __builtin_fmaf(yo, e, tt[j]);
+                    gy[mo][j] = dy;
+                }
             }
         }
     }
@@ -422,9 +499,8 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         for (int mo = 0; mo < HT; ++mo) {
             split4(dout[net][mo], dsh[mo], dsl[mo]);
             const T16 d_t = mtrans(dsh[mo], dsl[mo], ident);
-            const f4 dw = outer16h(d_t, h_t);  // [o = 16 mo + 4q + j][k = s]
-            lds_add4(acc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mo + 4 * q, dw, fa);
-            if (!SPARE) lds_add_rows(acc + A_::o_b2 + net * H + 16 * mo + 4 * q, rowsum16h(d_t), s, fa);
+            accp.w2(net, mo, d_t, h_t);  // [o = 16 mo + 4q + j][k = s]
+            if (!SPARE) accp.b2(net, mo, d_t);
         }
         if constexpr (H == 32) {
             const u2 h0_ = __builtin_bit_cast(u2, dsh[0]), h1_ = __builtin_bit_cast(u2, dsh[1]);
@@ -457,10 +533,8 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
             split4(da, dhi, dlo);
             const T16 d_t = mtrans(dhi, dlo, ident);
             const T16 h_t = tsplit(with_ones(h[l][net]), scrB, lane);
-            const f4 dw = outer16h(d_t, h_t);  // [k_out = 4q + j][k_in = s]
-            int* ah = acc + A_::o_h + l * A_::HID;
-            lds_add4(ah + (net * 16 + s) * A_::US + 4 * q, dw, fa);
-            if (!SPARE) lds_add_rows(ah + 2 * 16 * A_::US + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
+            accp.wh(l, net, d_t, h_t);  // [k_out = 4q + j][k_in = s]
+            if (!SPARE) accp.bh(l, net, d_t);
             h4 wh, wl;
             hl(bg, BImg::g_wh(l, net), wh, wl);
             dh[net] = mm3(wh, wl, dhi, dlo, zero);
@@ -480,11 +554,10 @@ __device__ __forceinline__ void layer_bwd16(const float* img, int* acc, FxAcc& f
         h4 dhi, dlo;
         split4(da, dhi, dlo);
         const T16 d_t = mtrans(dhi, dlo, ident);
-        lds_add_rows(acc + A_::o_b0 + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
+        accp.b0(net, d_t);
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
-            const f4 dw = outer16h(d_t, x_t[mm]);  // [u = 4q + j][f = 16 mm + s]
-            lds_add4(acc + A_::o_w0 + (net * H + 16 * mm + s) * A_::US + 4 * q, dw, fa);
+            accp.w0(net, mm, d_t, x_t[mm]);  // [u = 4q + j][f = 16 mm + s]
             h4 wh, wl;
             hl(bg, BImg::g_w0(net, mm), wh, wl);
             gx[mm] = mm3(wh, wl, dhi, dlo, gx[mm]);
@@ -622,11 +695,13 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
             int* acc = accb + c * ACC;
             const float* fc = img + R::C_OFF;
             if ((c & 1) == 0) {  // RealNVP(upper): conditioner = low half
-                layer_bwd16<H, L, SPARE>(img, acc, fa, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
+                LdsFxAccum<H, L> ap{acc, fa, s, q};
+                layer_bwd16<H, L, SPARE, false>(img, ap, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
                 unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
                 unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             } else {             // RealNVP(lower) behind BatchNorm + Affine
-                layer_bwd16<H, L, SPARE>(img, acc, fa, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
+                LdsFxAccum<H, L> ap{acc, fa, s, q};
+                layer_bwd16<H, L, SPARE, false>(img, ap, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             }
