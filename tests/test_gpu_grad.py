@@ -251,8 +251,9 @@ def test_flow_reversible_backward_zero_upstream(tnf):
     assert float(p.grad.abs().max()) == 0.0 and float(z.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("fp32_bwd", [0, 1])
 @pytest.mark.parametrize("D,S,L,M,N", [(64, 4, 2, 1, 600), (32, 2, 3, 3, 100), (64, 1, 1, 2, 40)])
-def test_forward_path_training_one_node(tnf, oracle, D, S, L, M, N):
+def test_forward_path_training_one_node(tnf, oracle, D, S, L, M, N, fp32_bwd):
     """Sampling with fresh batch statistics under autograd as ONE node (tnf_flow_forward_train_fwd/bwd_f32: the
     BatchNorm / Affine between coupling layers folded into the next kernel, gradients through the batch moments
     from the coupling backward kernels' fold sums): loss and gradients w.r.t. the parameter rows and the base draw
@@ -263,6 +264,15 @@ def test_forward_path_training_one_node(tnf, oracle, D, S, L, M, N):
     p0 = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float()
     om0 = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
     w = torch.tensor(rng.uniform(0.5, 1.5, (M, N))).float()
+    # the layer backward kernel of the chain: split-f16 (default) or fp32 MFMA
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, fp32_bwd))
+    try:
+        _one_node_body(tnf, oracle, nf, p0, om0, w, D, S, L, U)
+    finally:
+        tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, 0)
+
+
+def _one_node_body(tnf, oracle, nf, p0, om0, w, D, S, L, U):
     res = {}
     for fused in (True, False):
         nf.fused_batch_forward = fused

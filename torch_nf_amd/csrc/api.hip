@@ -77,6 +77,10 @@ int tnf_set_option(int32_t key, int32_t value) {
         g_flow_variant = value;
         return TNF_OK;
     }
+    if (key == TNF_OPT_TRAIN_BWD_FP32) {
+        g_train_bwd_fp32 = value;
+        return TNF_OK;
+    }
     if (key == TNF_OPT_LAYER_VARIANT) {
         g_layer_variant = value;
         return TNF_OK;

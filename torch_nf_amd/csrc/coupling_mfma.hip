@@ -363,6 +363,7 @@ bool mfma_supported(int D, int L, int U) {
 //   0: operands in registers, 2 tiles per wave iteration     1: operands in LDS, 2 tiles
 //   2: operands in LDS, 1 tile                               3: operands in registers, 1 tile
 int g_layer_variant = 0;
+int g_train_bwd_fp32 = 0;
 
 template <int H, int L, bool INV, int NT, bool LDSOP>
 static void launch_k(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {
@@ -795,7 +796,9 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
         a.g_fold = c == 0 ? nullptr : PQ;
         a.fold_stride = 2 * (int64_t)D;
         a.gcorr = (c == nl - 1) ? nullptr : kk;
-        rc = launch_coupling_backward_mfma_args(a, D, L, 0, st);
+        // split-f16 layer backward (flow_bwd_f16.hip) unless asked otherwise or it would spill (L = 3 without a spare unit)
+        if (g_train_bwd_fp32 || (L == 3 && U > 15)) rc = launch_coupling_backward_mfma_args(a, D, L, 0, st);
+        else rc = launch_coupling_backward_f16(a, D, L, st);
         if (rc) return rc;
         cur ^= 1;
     }

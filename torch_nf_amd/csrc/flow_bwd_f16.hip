@@ -315,6 +315,35 @@ struct FlowBwdArgs {
 // One coupling layer backwards on one tile.  x: conditioner half (= layer input and output);
 // y: in = transformed half of the OUTPUT, out = of the INPUT;  gx, gy: in = gradients wrt the layer's
 // outputs, out = wrt its inputs;  gl = d loss / d (sum of s) for this sample (natural log units).
+// index inside AccLayout of element k of the layer's parameter block (bijectors.py:222-235: per MLP layer
+// [W_t | W_s | b_t | b_s], W[in][out]); with SPARE the biases behind a tanh live in row 15 of the weight tiles
+template <int H, int L, bool SPARE>
+__device__ __forceinline__ int acc_src(int kk, int U) {
+    typedef AccLayout<H, L> A_;
+    if (kk < 2 * H * U + 2 * U) {
+        if (kk < 2 * H * U) return A_::o_w0 + (kk / U) * A_::US + kk % U;   // (net, f) rows are contiguous
+        return A_::o_b0 + ((kk - 2 * H * U) / U) * 16 + (kk - 2 * H * U) % U;
+    }
+    kk -= 2 * H * U + 2 * U;
+    const int hs = 2 * U * U + 2 * U;
+    if (kk < (L - 1) * hs) {
+        const int l = kk / hs, r = kk - l * hs;
+        if (r < 2 * U * U) {
+            const int net = r / (U * U), rr = r - net * U * U;
+            return A_::o_h + l * A_::HID + (net * 16 + rr / U) * A_::US + rr % U;
+        }
+        if (SPARE) return A_::o_h + l * A_::HID + (((r - 2 * U * U) / U) * 16 + 15) * A_::US + (r - 2 * U * U) % U;
+        return A_::o_h + l * A_::HID + 2 * 16 * A_::US + ((r - 2 * U * U) / U) * 16 + (r - 2 * U * U) % U;
+    }
+    kk -= (L - 1) * hs;
+    if (kk < 2 * U * H) {
+        const int net = kk / (U * H), rr = kk - net * U * H;
+        return A_::o_w2 + (net * 16 + rr / H) * A_::HS + rr % H;
+    }
+    if (SPARE) return A_::o_w2 + (((kk - 2 * U * H) / H) * 16 + 15) * A_::HS + (kk - 2 * U * H) % H;
+    return A_::o_b2 + (kk - 2 * U * H);
+}
+
 // Where a tile's weight-gradient contributions go.  LdsFxAccum: the whole-flow kernel (a wave meets every layer, so
 // the accumulators are shared fixed-point LDS words).  RegAccum: a kernel that stays on one layer keeps them in
 // registers and lets the MFMAs accumulate.
@@ -378,7 +407,7 @@ template <int H, int L, bool SPARE, bool FWD, class ACCP>
 __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float* scrA, float* scrB, int lane, int U,
                                             const f4 (&x)[(H + 15) / 16], f4 (&y)[(H + 15) / 16],
                                             f4 (&gx)[(H + 15) / 16], f4 (&gy)[(H + 15) / 16], float gl,
-                                            const float* kc = nullptr) {
+                                            const float* kc = nullptr, float kmask = 1.f) {
     typedef F16Image<H, L> FImg;
     typedef B16Image<H, L> BImg;
     typedef RevImage<H, L> R;
@@ -471,7 +500,7 @@ __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float*
                 const float e = __builtin_amdgcn_exp2f(sv[j]);
                 if (FWD) {
                     float g = gy[mo][j];
-                    if (kc) g += __builtin_fmaf(kc[2 * H + 16 * mo + j], __builtin_fmaf(y[mo][j], e, tt[j]), kc[16 * mo + j]);
+                    if (kc) g += kmask * __builtin_fmaf(kc[2 * H + 16 * mo + j], __builtin_fmaf(y[mo][j], e, tt[j]), kc[16 * mo + j]);
                     const float dy = g * e;
                     dout[0][mo][j] = g;
                     dout[1][mo][j] = __builtin_fmaf(g * y[mo][j], e, gl);
@@ -756,29 +785,7 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
             if (!(c & 1)) continue;
             src = A_::o_fold + (k - P);
         } else {
-            int kk = k;
-            if (kk < 2 * H * U + 2 * U) {
-                if (kk < 2 * H * U) src = A_::o_w0 + (kk / U) * A_::US + kk % U;   // (net, f) rows are contiguous
-                else src = A_::o_b0 + ((kk - 2 * H * U) / U) * 16 + (kk - 2 * H * U) % U;
-            } else {
-                kk -= 2 * H * U + 2 * U;
-                const int hs = 2 * U * U + 2 * U;
-                if (kk < (L - 1) * hs) {
-                    const int l = kk / hs, r = kk - l * hs;
-                    if (r < 2 * U * U) {
-                        const int net = r / (U * U), rr = r - net * U * U;
-                        src = A_::o_h + l * A_::HID + (net * 16 + rr / U) * A_::US + rr % U;
-                    } else if (SPARE) src = A_::o_h + l * A_::HID + (((r - 2 * U * U) / U) * 16 + 15) * A_::US + (r - 2 * U * U) % U;
-                    else src = A_::o_h + l * A_::HID + 2 * 16 * A_::US + ((r - 2 * U * U) / U) * 16 + (r - 2 * U * U) % U;
-                } else {
-                    kk -= (L - 1) * hs;
-                    if (kk < 2 * U * H) {
-                        const int net = kk / (U * H), rr = kk - net * U * H;
-                        src = A_::o_w2 + (net * 16 + rr / H) * A_::HS + rr % H;
-                    } else if (SPARE) src = A_::o_w2 + (((kk - 2 * U * H) / H) * 16 + 15) * A_::HS + (kk - 2 * U * H) % H;
-                    else src = A_::o_b2 + (kk - 2 * U * H);
-                }
-            }
+            src = acc_src<H, L, SPARE>(k, U);
         }
         const float v = (float)acc[src] * unfx + poison;
         if (k < P) atomicAdd(gp + (c >> 1) * a.stage + ((c & 1) ? a.low_off : 0) + k, v);
@@ -792,6 +799,212 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
         tot += __shfl_xor(tot, 8);
         if (lane == 0) atomicAdd(a.glp_sum + mp, tot * isc);
     }
+}
+
+// ---------------------------------------------------------------------------
+// One forward-direction coupling layer backwards with its INPUT saved (the training-mode chain of coupling_mfma.hip:
+// sampling with fresh batch statistics under autograd).  Same tile code as above, split-f16 contractions; a wave
+// stays on the layer, so the weight gradients accumulate in registers inside the MFMAs and leave once.
+//   BwdArgs as for coupling_bwd_mfma_kernel: fold (A | B applied to the saved input), g_fold (dA | dB sums),
+//   gcorr (k0 | k1: upstream gradient g + k0 + k1 * output), ld_scale * g_ld on the sum of s.
+// ---------------------------------------------------------------------------
+constexpr int kLayerNW = 8;
+
+template <int H, int L, bool SPARE>
+__global__ void __launch_bounds__(kLayerNW * 64)
+coupling_bwd_f16_kernel(BwdArgs a) {
+    typedef RevImage<H, L> R;
+    typedef AccLayout<H, L> A_;
+    constexpr int D = 2 * H;
+    constexpr int HT = (H + 15) / 16;
+    constexpr int NW = kLayerNW;
+    static_assert(R::FLOATS >= A_::INTS, "the flush reuses the image area");
+    __shared__ __attribute__((aligned(16))) float lds[R::FLOATS + NW * kScr];
+    float* img = lds;
+    float* cst = lds + R::C_OFF;  // A | B | k0 | k1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int64_t m = grid_m();
+    if (m >= a.M) return;
+    const int64_t mp = a.Mp == 1 ? 0 : m;
+    const int U = a.U;
+    const float* prow = a.params + mp * a.pstride;
+    float* scrA = lds + R::FLOATS + wave * kScr;
+    if (wave == 0) build_f16_image<H, L>(img + R::F_OFF, prow, U, lane);
+    if (wave == 1) build_b16_image<H, L>(img + R::B_OFF, prow, U, lane);
+    const bool has_corr = a.gcorr != nullptr;
+    for (int i = threadIdx.x; i < 2 * D; i += NW * 64) {
+        cst[i] = a.fold ? a.fold[mp * a.fold_stride + i] : (i < D ? 1.f : 0.f);
+        cst[2 * D + i] = has_corr ? a.gcorr[i] : 0.f;
+    }
+    __syncthreads();
+
+    const int c_off = a.upper ? 0 : H, t_off = a.upper ? H : 0;
+    const float* zb = a.z + m * a.N * D;
+    const float* gzo = a.g_zout + m * a.N * D;
+    const float* gld = a.g_ld + m * a.N;
+    float* gzb = a.g_z + m * a.N * D;
+    const float* cx = cst + c_off + 4 * q;  // this lane's conditioner / transformed features
+    const float* cy = cst + t_off + 4 * q;
+    RegAccum<H, L> ra;
+    ra.clear();
+    f4 dAx[HT], dBx[HT], dAy[HT], dBy[HT];
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mm = 0; mm < HT; ++mm) dAx[mm] = dBx[mm] = dAy[mm] = dBy[mm] = zero;
+
+    const int64_t ntiles = (a.N + 15) >> 4;
+    const int64_t tstep = (int64_t)gridDim.x * NW;
+    f4 nxs[HT], nys[HT];  // the next tile's saved input, in flight while this tile computes
+    {
+        int64_t r0 = ((int64_t)blockIdx.x * NW + wave) * 16 + s;
+        if (r0 >= a.N) r0 = a.N - 1;
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            nxs[mm] = *reinterpret_cast<const f4*>(zb + r0 * D + 4 * q + 16 * mm + c_off);
+            nys[mm] = *reinterpret_cast<const f4*>(zb + r0 * D + 4 * q + 16 * mm + t_off);
+        }
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += tstep) {
+        const int64_t row = tile * 16 + s;
+        const bool row_ok = row < a.N;
+        const int64_t rowc = row_ok ? row : a.N - 1;
+        int64_t nrow = (tile + tstep) * 16 + s;
+        if (nrow >= a.N) nrow = a.N - 1;
+        f4 xs[HT], ys[HT], x[HT], y[HT], gx[HT], gy[HT];
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            const float* gr = gzo + rowc * D + 4 * q + 16 * mm;
+            xs[mm] = nxs[mm];
+            ys[mm] = nys[mm];
+            nxs[mm] = *reinterpret_cast<const f4*>(zb + nrow * D + 4 * q + 16 * mm + c_off);
+            nys[mm] = *reinterpret_cast<const f4*>(zb + nrow * D + 4 * q + 16 * mm + t_off);
+            gx[mm] = row_ok ? *reinterpret_cast<const f4*>(gr + c_off) : zero;
+            gy[mm] = row_ok ? *reinterpret_cast<const f4*>(gr + t_off) : zero;
+            const f4 ax = *reinterpret_cast<const f4*>(cx + 16 * mm), bx = *reinterpret_cast<const f4*>(cx + D + 16 * mm);
+            const f4 ay = *reinterpret_cast<const f4*>(cy + 16 * mm), by = *reinterpret_cast<const f4*>(cy + D + 16 * mm);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[mm][j] = __builtin_fmaf(xs[mm][j], ax[j], bx[j]);
+                y[mm][j] = __builtin_fmaf(ys[mm][j], ay[j], by[j]);
+            }
+            if (has_corr && row_ok) {  // the conditioner half of the output is x itself
+                const f4 k0 = *reinterpret_cast<const f4*>(cx + 2 * D + 16 * mm), k1 = *reinterpret_cast<const f4*>(cx + 3 * D + 16 * mm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gx[mm][j] += __builtin_fmaf(k1[j], x[mm][j], k0[j]);
+            }
+        }
+        const float gl = row_ok ? a.ld_scale * gld[rowc] : 0.f;
+        layer_bwd16<H, L, SPARE, true>(img, ra, scrA, scrA, lane, U, x, y, gx, gy, gl, has_corr ? cy + 2 * D : nullptr,
+                                       row_ok ? 1.f : 0.f);
+        // back through the fold: g w.r.t. the saved input, and the fold-constant sums
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            const f4 ax = *reinterpret_cast<const f4*>(cx + 16 * mm), ay = *reinterpret_cast<const f4*>(cy + 16 * mm);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dAx[mm][j] = __builtin_fmaf(gx[mm][j], xs[mm][j], dAx[mm][j]);
+                dBx[mm][j] += gx[mm][j];
+                dAy[mm][j] = __builtin_fmaf(gy[mm][j], ys[mm][j], dAy[mm][j]);
+                dBy[mm][j] += gy[mm][j];
+                gx[mm][j] *= ax[j];
+                gy[mm][j] *= ay[j];
+            }
+            if (row_ok) {
+                float* gr = gzb + row * D + 4 * q + 16 * mm;
+                *reinterpret_cast<f4*>(gr + c_off) = gx[mm];
+                *reinterpret_cast<f4*>(gr + t_off) = gy[mm];
+            }
+        }
+    }
+
+    // ---- flush: register accumulators -> LDS (waves in turn, plain adds) -> one global atomic per parameter ----
+    __syncthreads();
+    float* gacc = lds;  // AccLayout, floats
+    for (int i = threadIdx.x; i < A_::INTS; i += NW * 64) gacc[i] = 0.f;
+    __syncthreads();
+    auto add4 = [&](float* p, f4 v) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] += v[j];
+    };
+    auto red16 = [&](float v) -> float {
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        return v;
+    };
+    for (int turn = 0; turn < NW; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm) {
+                    add4(gacc + A_::o_w0 + (net * H + 16 * mm + s) * A_::US + 4 * q, ra.W0[net][mm]);
+                    add4(gacc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mm + 4 * q, ra.W2[net][mm]);
+                    if (!SPARE && s == 0) add4(gacc + A_::o_b2 + net * H + 16 * mm + 4 * q, ra.B2[net][mm]);
+                }
+#pragma unroll
+                for (int l = 0; l < L - 1; ++l) {
+                    add4(gacc + A_::o_h + l * A_::HID + (net * 16 + s) * A_::US + 4 * q, ra.Wh[l][net]);
+                    if (!SPARE && s == 0) add4(gacc + A_::o_h + l * A_::HID + 2 * 16 * A_::US + net * 16 + 4 * q, ra.Bh[l][net]);
+                }
+                if (s == 0) add4(gacc + A_::o_b0 + net * 16 + 4 * q, ra.B0[net]);
+            }
+            if (a.g_fold) {
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ax = red16(dAx[mm][j]), bx = red16(dBx[mm][j]);
+                        const float ay = red16(dAy[mm][j]), by = red16(dBy[mm][j]);
+                        if (s == 0) {
+                            const int fx = c_off + 16 * mm + 4 * q + j, fy = t_off + 16 * mm + 4 * q + j;
+                            gacc[A_::o_fold + fx] += ax;
+                            gacc[A_::o_fold + D + fx] += bx;
+                            gacc[A_::o_fold + fy] += ay;
+                            gacc[A_::o_fold + D + fy] += by;
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
+    float* gout = a.g_params + mp * a.gpstride;
+    for (int k = threadIdx.x; k < P; k += NW * 64) atomicAdd(gout + k, gacc[acc_src<H, L, SPARE>(k, U)]);
+    if (a.g_fold) {
+        float* gfo = a.g_fold + mp * a.fold_stride;
+        for (int i = threadIdx.x; i < 2 * D; i += NW * 64) atomicAdd(gfo + i, gacc[A_::o_fold + i]);
+    }
+}
+
+template <int H, int L>
+static void launch_layer_f16(const BwdArgs& a, dim3 grid, hipStream_t st) {
+    if (a.U <= 15) hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, true>), grid, dim3(kLayerNW * 64), 0, st, a);
+    else hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, false>), grid, dim3(kLayerNW * 64), 0, st, a);
+}
+
+// forward-direction layers only (inverse = 0); shapes of mfma_supported(); g_z_out, g_ld, g_z required
+int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, hipStream_t st) {
+    if (!(D == 64 || D == 32) || L < 1 || L > 3 || a.U < 1 || a.U > 16)
+        return fail(TNF_EUNSUPPORTED, "coupling_backward_f16: D=%d L=%d U=%d", D, L, a.U);
+    if (a.N <= 0) return TNF_OK;
+    const int64_t ntiles = (a.N + 15) / 16;
+    int64_t bx = (ntiles + kLayerNW - 1) / kLayerNW;
+    int64_t cap = (256 + a.M - 1) / a.M;
+    if (bx > cap) bx = cap;
+    const dim3 grid = grid_xm(bx, a.M);
+    if (D == 64) {
+        if (L == 1) launch_layer_f16<32, 1>(a, grid, st);
+        else if (L == 2) launch_layer_f16<32, 2>(a, grid, st);
+        else launch_layer_f16<32, 3>(a, grid, st);
+    } else {
+        if (L == 1) launch_layer_f16<16, 1>(a, grid, st);
+        else if (L == 2) launch_layer_f16<16, 2>(a, grid, st);
+        else launch_layer_f16<16, 3>(a, grid, st);
+    }
+    return check_launch("coupling_backward_f16");
 }
 
 // ---------------------------------------------------------------------------

@@ -66,6 +66,7 @@ __host__ __device__ inline FlowLayout flow_layout(int D, int S, int L, int U) {
 extern int g_force_generic;
 extern int g_flow_variant;   // flow_fused.hip
 extern int g_layer_variant;  // coupling_mfma.hip
+extern int g_train_bwd_fp32; // coupling_mfma.hip
 extern int g_cond_variant;   // cond_flow.hip
 
 // ---- kernels implemented in the .hip files ----------------------------------
@@ -186,6 +187,7 @@ struct BwdArgs {
                           // (batch-statistics backward of the fold behind the layer, forward direction only)
 };
 int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);
+int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, hipStream_t st);  // forward direction, split-f16 (flow_bwd_f16.hip)
 int launch_coupling_backward_mfma(const float* z, const float* params, const float* g_zout,
                                   const float* g_ld, float* g_z, float* g_params, int64_t M, int64_t Mp,
                                   int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
