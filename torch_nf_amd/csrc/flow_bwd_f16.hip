@@ -855,8 +855,8 @@ coupling_bwd_f16_kernel(BwdArgs a) {
 
     const int64_t ntiles = (a.N + 15) >> 4;
     const int64_t tstep = (int64_t)gridDim.x * NW;
-    f4 nxs[HT], nys[HT];  // the next tile's saved input, in flight while this tile computes
-    {
+    f4 nxs[HT], nys[HT];  // the next tile's saved input, in flight while this tile computes (prefetching g as well
+    {                     // gained nothing: its loads already overlap the forward recompute)
         int64_t r0 = ((int64_t)blockIdx.x * NW + wave) * 16 + s;
         if (r0 >= a.N) r0 = a.N - 1;
 #pragma unroll
@@ -888,15 +888,19 @@ coupling_bwd_f16_kernel(BwdArgs a) {
                 x[mm][j] = __builtin_fmaf(xs[mm][j], ax[j], bx[j]);
                 y[mm][j] = __builtin_fmaf(ys[mm][j], ay[j], by[j]);
             }
-            if (has_corr && row_ok) {  // the conditioner half of the output is x itself
+        }
+        const float gl = row_ok ? a.ld_scale * gld[rowc] : 0.f;
+        layer_bwd16<H, L, SPARE, true>(img, ra, scrA, scrA, lane, U, x, y, gx, gy, gl, has_corr ? cy + 2 * D : nullptr,
+                                       row_ok ? 1.f : 0.f);
+        if (has_corr && row_ok) {  // the conditioner half of the output is x itself; added here (the layer code is linear
+                                   // in gx) so that the g loads stay in flight during the forward recompute
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
                 const f4 k0 = *reinterpret_cast<const f4*>(cx + 2 * D + 16 * mm), k1 = *reinterpret_cast<const f4*>(cx + 3 * D + 16 * mm);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gx[mm][j] += __builtin_fmaf(k1[j], x[mm][j], k0[j]);
             }
         }
-        const float gl = row_ok ? a.ld_scale * gld[rowc] : 0.f;
-        layer_bwd16<H, L, SPARE, true>(img, ra, scrA, scrA, lane, U, x, y, gx, gy, gl, has_corr ? cy + 2 * D : nullptr,
-                                       row_ok ? 1.f : 0.f);
         // back through the fold: g w.r.t. the saved input, and the fold-constant sums
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
