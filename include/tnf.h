@@ -164,6 +164,13 @@ int64_t tnf_maf_num_params(int32_t D, int32_t num_layers, int32_t num_units);
 int tnf_maf(int32_t dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
             int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_layers, int32_t num_units,
             int32_t inverse, int64_t params_row_stride, void* stream);
+/* MAF.inverse_and_log_det (bijectors.py:758-764) with the per-dimension f_alpha(z) (M,N,D) as an extra output.
+ * The backward of the sampling direction (autograd through MAF.forward_and_log_det, bijectors.py:752-754) is built on
+ * it: x solves G(x, theta) = omega with G the inverse map, whose Jacobian is triangular with diagonal e^-alpha. */
+int tnf_maf_inverse_alpha(int32_t dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
+                          void* alpha_out, int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t num_layers,
+                          int32_t num_units, int64_t params_row_stride, void* stream);
+
 int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
                      const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N,
                      int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,

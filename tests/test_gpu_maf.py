@@ -268,3 +268,56 @@ def test_ar_flow_training_one_kernel_backward(tnf, oracle, D, L, U, M, Mp, N, su
     torch.testing.assert_close(res[True][0], loss_o.detach(), rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(res[True][1], res[False][1], rtol=2e-4, atol=2e-5 * scale)
     torch.testing.assert_close(res[True][1], pr.grad, rtol=5e-4, atol=5e-5 * scale)
+
+
+@pytest.mark.parametrize("D,L,U,M,Mp,N,dt", [(6, 2, 15, 3, 3, 40, torch.float32), (5, 1, 20, 2, 1, 33, torch.float32),
+                                              (8, 3, 16, 1, 1, 64, torch.float64), (16, 2, 32, 2, 2, 50, torch.float32)])
+def test_maf_sampling_direction_backward(tnf, oracle, D, L, U, M, Mp, N, dt):
+    """Autograd through MAF.forward_and_log_det (the reference differentiates its D - 1 passes,
+    bijectors.py:752-754): here the implicit-function backward of ops._MafFn -- D + 1 launches of the
+    inverse-direction backward kernel around the per-dimension alpha of tnf_maf_inverse_alpha.  Gradients w.r.t.
+    the parameter rows and the base draw against torch autograd through the oracle's iterated forward."""
+    rng = np.random.RandomState(D * 10 + L)
+    np.random.seed(D + L)
+    maf = tnf.MAF(D, L, U)
+    Ms = [Mk[0].numpy() for Mk in maf.Ms]
+    n = maf.count_num_params()
+    p0 = torch.tensor(rng.normal(0, 0.3, (Mp, n))).to(dt)
+    om0 = torch.tensor(rng.normal(0, 1, (M, N, D))).to(dt)
+    wz = torch.tensor(rng.normal(0, 1, (M, N, D))).to(dt)
+    wl = torch.tensor(rng.normal(0, 1, (M, N))).to(dt)
+    p, om = p0.clone().cuda().requires_grad_(), om0.clone().cuda().requires_grad_()
+    z, ld = maf(om, p)
+    ((z * wz.cuda()).sum() + (ld * wl.cuda()).sum()).backward()
+    pr, omr = p0.clone().requires_grad_(), om0.clone().requires_grad_()
+    zr, ldr = oracle.maf(omr, pr, D, maf.num_layers, maf.num_units, Ms, False)
+    ((zr * wz).sum() + (ldr * wl).sum()).backward()
+    tol = dict(rtol=1e-9, atol=1e-9) if dt == torch.float64 else dict(rtol=2e-3, atol=2e-4 * float(pr.grad.abs().max()))
+    torch.testing.assert_close(z.detach().cpu(), zr.detach(), rtol=1e-4 if dt == torch.float32 else 1e-10,
+                               atol=1e-4 if dt == torch.float32 else 1e-10)
+    torch.testing.assert_close(p.grad.cpu(), pr.grad, **tol)
+    tol_o = dict(rtol=1e-9, atol=1e-9) if dt == torch.float64 else dict(rtol=2e-3, atol=2e-4 * float(omr.grad.abs().max()))
+    torch.testing.assert_close(om.grad.cpu(), omr.grad, **tol_o)
+
+
+def test_ar_flow_sampling_with_gradients(tnf, oracle):
+    """NormFlow(arch_type='AR') sampling with fresh batch statistics under autograd (an EFN-style objective on the
+    reference's default architecture): MAF sampling-direction backward + batch-statistics BatchNorm + Affine, against
+    torch autograd through the oracle."""
+    D, L, U, M, N = 6, 2, 15, 2, 300
+    np.random.seed(11)
+    rng = np.random.RandomState(11)
+    nf = tnf.NormFlow(D, True, "AR", 1, L, U)
+    Ms = [Mk[0].numpy() for Mk in nf.bijectors[0].Ms]
+    p0 = torch.tensor(rng.normal(0, 0.2, (M, nf.D_params))).float()
+    omega = rng.normal(0, 1, (M, N, D))
+    p = p0.clone().cuda().requires_grad_()
+    z, lq = nf._forward_from(omega, p, freeze_bn=False)
+    loss = lq.mean() + (z ** 2).mean()
+    loss.backward()
+    pr = p0.clone().requires_grad_()
+    zr, lqr, _ = oracle.ar_flow_forward(omega, pr, D, nf.num_layers, nf.num_units, Ms, None)
+    loss_r = lqr.mean() + (zr ** 2).mean()
+    loss_r.backward()
+    torch.testing.assert_close(loss.detach().cpu().double(), loss_r.detach().double(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(p.grad.cpu(), pr.grad, rtol=5e-3, atol=2e-4 * float(pr.grad.abs().max()))

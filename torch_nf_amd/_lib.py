@@ -85,6 +85,8 @@ SIGNATURES = {
                                                       _i32, _i32, _i64, ctypes.c_float, _vp, _i64, _vp]),
     "tnf_flow_forward_train_bwd_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                                       _i32, _i32, _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
+    "tnf_maf_inverse_alpha": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i64,
+                                             _vp]),
     "tnf_ar_flow_train_supported": (ctypes.c_int, [_i32, _i32, _i32]),
     "tnf_ar_flow_bwd_workspace_bytes": (_i64, [_i64, _i32]),
     "tnf_ar_flow_log_prob_bwd_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,

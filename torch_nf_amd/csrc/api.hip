@@ -383,6 +383,24 @@ int tnf_ar_flow_log_prob_bwd_f32(const float* z, const float* params, const floa
                                    N, D, L, U, pstride, gpstride, as_stream(stream));
 }
 
+/* MAF.inverse_and_log_det with the per-dimension f_alpha(z) (M,N,D) as an extra output (generic kernel, float32 /
+ * float64): the diagonal of the inverse map's Jacobian is e^-alpha, which the backward of the SAMPLING direction
+ * needs (ops._MafFn: implicit differentiation of G(x, theta) = omega through the inverse-direction backward). */
+int tnf_maf_inverse_alpha(int32_t dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
+                          void* alpha_out, int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U,
+                          int64_t pstride, void* stream) {
+    if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_maf_inverse_alpha: dtype %d", dtype);
+    int rc = check_mnd("tnf_maf_inverse_alpha", M_z, M_p, N, D);
+    if (rc) return rc;
+    if (L < 1 || U < 1) return fail(TNF_EINVAL, "tnf_maf_inverse_alpha: L=%d U=%d", L, U);
+    if (pstride < tnf_maf_num_params(D, L, U))
+        return fail(TNF_EINVAL, "tnf_maf_inverse_alpha: params row has %lld elements, layer needs %lld", (long long)pstride,
+                    (long long)tnf_maf_num_params(D, L, U));
+    if (!z || !params || !masks || !z_out || !log_det || !alpha_out) return fail(TNF_EINVAL, "tnf_maf_inverse_alpha: NULL pointer");
+    if (N == 0) return TNF_OK;
+    return launch_maf(dtype, z, params, masks, z_out, log_det, M_z, M_p, N, D, L, U, 1, pstride, as_stream(stream), alpha_out);
+}
+
 int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
                      const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D,
                      int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* stream) {

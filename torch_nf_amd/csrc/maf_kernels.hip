@@ -70,8 +70,8 @@ __device__ __forceinline__ int maf_net(const T* __restrict__ params, const T* __
 template <typename T>
 __global__ void __launch_bounds__(256)
 maf_kernel(const T* __restrict__ z, const T* __restrict__ params, const T* __restrict__ masks,
-           T* __restrict__ z_out, T* __restrict__ log_det, int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U,
-           int inverse, int64_t pstride, int TS, int W) {
+           T* __restrict__ z_out, T* __restrict__ log_det, T* __restrict__ alpha_out, int64_t Mz, int64_t Mp, int64_t N,
+           int D, int L, int U, int inverse, int64_t pstride, int TS, int W) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x;
@@ -97,6 +97,7 @@ maf_kernel(const T* __restrict__ z, const T* __restrict__ params, const T* __res
         for (int idx = tid; idx < ts * D; idx += 256) {
             const int i = idx / D, d = idx - i * D;
             zo[(int64_t)i * D + d] = (zc[i * W + d] - bm[cur][i * W + d]) / maf_exp<T>(ba[cur][i * W + d]);
+            if (alpha_out) alpha_out[(m * N + n0 + i) * D + d] = ba[cur][i * W + d];  // per-dimension f_alpha(z)
         }
         if (tid < ts) {
             T acc = 0;
@@ -138,7 +139,8 @@ static int maf_tile(int D, int U, int L, size_t esz, int planes, int64_t N, int*
 }
 
 int launch_maf(int dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
-               int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st) {
+               int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st,
+               void* alpha_out) {
     const int64_t M = Mz > Mp ? Mz : Mp;
     const size_t esz = dtype == TNF_F64 ? 8 : 4;
     int W;
@@ -152,13 +154,13 @@ int launch_maf(int dtype, const void* z, const void* params, const void* masks, 
         auto k = maf_kernel<float>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const float*)z, (const float*)params, (const float*)masks,
-                           (float*)z_out, (float*)log_det, Mz, Mp, N, D, L, U, inverse, pstride, TS, W);
+                           (float*)z_out, (float*)log_det, (float*)alpha_out, Mz, Mp, N, D, L, U, inverse, pstride, TS, W);
     } else {
         auto k = maf_kernel<double>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const double*)z, (const double*)params,
-                           (const double*)masks, (double*)z_out, (double*)log_det, Mz, Mp, N, D, L, U, inverse,
-                           pstride, TS, W);
+                           (const double*)masks, (double*)z_out, (double*)log_det, (double*)alpha_out, Mz, Mp, N, D, L, U,
+                           inverse, pstride, TS, W);
     }
     return check_launch("maf");
 }

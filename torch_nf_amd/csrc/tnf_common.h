@@ -254,7 +254,7 @@ int launch_maf_backward_mfma(const float* z, const float* params, const float* m
                              const float* g_ld, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int D,
                              int L, int U, int64_t pstride, int64_t gpstride, hipStream_t st);
 int launch_maf(int dtype, const void* z, const void* params, const void* masks, void* z_out, void* log_det,
-               int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st);
+               int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st, void* alpha_out = nullptr);
 int launch_maf_backward(int dtype, const void* z, const void* params, const void* masks, const void* g_zout,
                         const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N, int D, int L,
                         int U, int64_t pstride, int64_t gpstride, hipStream_t st);

@@ -577,12 +577,41 @@ def maf_raw(z, params, masks, D, L, U, inverse):
     return z_out, log_det
 
 
+def maf_inverse_alpha_raw(x, params, masks, D, L, U):
+    """tnf_maf_inverse_alpha: per-dimension f_alpha(x) (M, N, D) of MAF.inverse_and_log_det on the compute device."""
+    dev = _lib.require_device()
+    xc = _stage(x, dev)
+    pc, pstride = _rows(params, dev)
+    mk = masks if (masks.device == dev and masks.dtype == x.dtype) else _stage(masks.to(x.dtype), dev)
+    Mz, N = xc.shape[0], xc.shape[1]
+    Mp = pc.shape[0]
+    M = _bcast_M(Mz, Mp)
+    out = torch.empty((M, N, D), dtype=x.dtype, device=dev)
+    ld = torch.empty((M, N), dtype=x.dtype, device=dev)
+    alpha = torch.empty((M, N, D), dtype=x.dtype, device=dev)
+    if N > 0:
+        check(lib.tnf_maf_inverse_alpha(_dtype_code(x), xc.data_ptr(), pc.data_ptr(), mk.data_ptr(), out.data_ptr(),
+                                        ld.data_ptr(), alpha.data_ptr(), Mz, Mp, N, D, L, U, pstride, _lib.stream_ptr()))
+    return alpha
+
+
 class _MafFn(torch.autograd.Function):
+    """MAF in either direction.  The backward of the sampling direction (the reference differentiates the D - 1
+    passes of bijectors.py:752-754) uses the implicit function theorem instead: the sample x solves
+    G(x, theta) = omega with G the one-pass inverse map, whose Jacobian G_x is triangular in the autoregressive order
+    with diagonal e^-alpha.  With K(g_out, g_ld) the inverse-direction backward kernel (K_z = G_x^T g_out + A_x^T g_ld,
+    K_theta likewise; A = sum alpha), the total gradient w.r.t. x is w = g_x + A_x^T g_ld, v = G_x^-T w is reached
+    exactly by D sweeps of  v <- v + e^alpha (g_x - K_z(v, -g_ld))  (the error moves strictly along the
+    autoregressive order), and then  g_omega = v,  g_theta = -K_theta(v, -g_ld)."""
+
     @staticmethod
     def forward(ctx, z, params, masks, D, L, U, inverse):
         z_out, log_det = maf_raw(z, params, masks, D, L, U, inverse)
-        ctx.save_for_backward(z, params, masks)
-        ctx.cfg = (D, L, U, inverse)
+        if inverse:
+            ctx.save_for_backward(z, params, masks)
+        else:
+            ctx.save_for_backward(z_out, params, masks)  # the sample: everything is evaluated there
+        ctx.cfg = (D, L, U, inverse, z.shape[0])
         return z_out, log_det
 
     @staticmethod
@@ -590,13 +619,24 @@ class _MafFn(torch.autograd.Function):
         from . import grad
 
         z, params, masks = ctx.saved_tensors
-        D, L, U, inverse = ctx.cfg
-        if not inverse:
-            raise NotImplementedError(
-                "torch_nf_amd: autograd through MAF.forward_and_log_det (the D-1 pass sampling direction) is not "
-                "implemented; differentiate log_prob / inverse_and_log_det instead")
-        gz, gp = grad.maf_backward(z, params, masks, g_z, g_ld, D, L, U)
-        return gz, gp, None, None, None, None, None
+        D, L, U, inverse, Mz = ctx.cfg
+        if inverse:
+            gz, gp = grad.maf_backward(z, params, masks, g_z, g_ld, D, L, U)
+            return gz, gp, None, None, None, None, None
+        x = z.detach()
+        dev = _lib.require_device()
+        gx = torch.zeros_like(x) if g_z is None else g_z.to(x.dtype)
+        gl = torch.zeros(x.shape[:2], dtype=x.dtype, device=x.device) if g_ld is None else g_ld.to(x.dtype)
+        ea = torch.exp(maf_inverse_alpha_raw(x, params.detach(), masks, D, L, U)).to(x.device)
+        v = ea * gx
+        for _ in range(D):  # a strictly triangular D x D coupling is nilpotent of index <= D: exact after D sweeps
+            kz, _gp = grad.maf_backward(x, params, masks, v, -gl, D, L, U)
+            v = v + ea * (gx - kz)
+        _kz, gp = grad.maf_backward(x, params, masks, v, -gl, D, L, U)
+        g_omega = v
+        if Mz != v.shape[0]:
+            g_omega = v.sum(0, keepdim=True)
+        return g_omega, -gp, None, None, None, None, None
 
 
 def maf(z, params, masks, D, L, U, inverse):
