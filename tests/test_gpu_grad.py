@@ -312,3 +312,32 @@ def _one_node_body(tnf, oracle, nf, p0, om0, w, D, S, L, U):
     fd = (oracle_loss(om0 + h * dirn) - oracle_loss(om0 - h * dirn)) / (2 * h)
     got = float((om.grad.cpu() * dirn).sum())
     assert abs(got - fd) <= 2e-2 * max(1.0, abs(fd)), (got, fd)
+
+
+@pytest.mark.parametrize("scale", [1e-7, 3e4])
+def test_layer_chains_keep_precision_at_any_loss_scale(tnf, oracle, scale):
+    """The split-f16 layer backward kernels of the per-layer training pair and of the sampling chain work on
+    gradients rescaled by a power of two taken from the chain's largest upstream gradient; without it a loss like
+    mean over 2^19 samples (g ~ 1e-6) would put the deltas' low halves into the f16 subnormals."""
+    D, S, L, U, N = 64, 2, 2, 15, 500
+    rng = np.random.RandomState(7)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.1, (1, nf.D_params))).float()
+    z0 = torch.tensor(rng.normal(0, 1, (1, N, D))).float()
+    stats = [(torch.zeros(D), torch.ones(D))] * (2 * S)
+    # (a) per-layer log_prob pair
+    nf.reversible_training = False
+    p = p0.clone().cuda().requires_grad_()
+    (nf.log_prob(z0.cuda(), p).mean() * scale).backward()
+    pr = p0.clone().requires_grad_()
+    (oracle.flow_log_prob(z0, pr, D, S, L, U, stats).mean() * scale).backward()
+    torch.testing.assert_close(p.grad.cpu() / scale, pr.grad / scale, rtol=5e-4, atol=5e-5)
+    # (b) sampling chain with fresh statistics
+    p = p0.clone().cuda().requires_grad_()
+    z, lq = nf._forward_from(z0.double().numpy(), p, freeze_bn=False)
+    ((lq.mean() + (z ** 2).mean()) * scale).backward()
+    pr = p0.clone().requires_grad_()
+    zr, lqr, _ = oracle.flow_forward(z0.double().numpy(), pr, D, S, L, U, None)
+    ((lqr.mean() + (zr ** 2).mean()) * scale).backward()
+    sp = float((pr.grad / scale).abs().max())
+    torch.testing.assert_close(p.grad.cpu() / scale, pr.grad / scale, rtol=5e-3, atol=2e-4 * sp)

@@ -700,7 +700,7 @@ static TrainWs train_ws(int64_t M, int64_t Mp, int64_t N, int D, int S, int L) {
     w.images = w.ldc + round16(Mp * (int64_t)sizeof(float));
     w.gfold = w.images + round16(Mp * 2 * S * mfma_image_floats(D, L) * (int64_t)sizeof(float));
     // g_fold (Mp, 2S, 2, D) followed by the per-row sums of g_log_prob (Mp): zeroed together
-    w.ldbuf = w.gfold + round16((Mp * 2 * S * 2 * D + Mp) * (int64_t)sizeof(float));
+    w.ldbuf = w.gfold + round16((Mp * 2 * S * 2 * D + Mp + 1) * (int64_t)sizeof(float));  // + max |g_log_prob|
     w.gbuf = w.ldbuf + round16(M * N * (int64_t)sizeof(float));
     w.total = w.gbuf + 2 * round16(M * N * D * (int64_t)sizeof(float));
     return w;
@@ -802,8 +802,11 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, images, M_p, D, S, L, U, pstride, 1, st);
     if (rc) return rc;
     float* glp_sum = gfold + M_p * 2 * S * 2 * D;
-    if (hipMemsetAsync(gfold, 0, (size_t)(M_p * 2 * S * 2 * D + M_p) * sizeof(float), st) != hipSuccess)
+    unsigned* gmaxw = reinterpret_cast<unsigned*>(glp_sum + M_p);
+    if (hipMemsetAsync(gfold, 0, (size_t)(M_p * 2 * S * 2 * D + M_p + 1) * sizeof(float), st) != hipSuccess)
         return fail(TNF_ELAUNCH, "tnf_flow_log_prob_bwd_f32: memset failed");
+    rc = launch_gmax(g_log_prob, M * N, gmaxw, st);
+    if (rc) return rc;
     const FlowLayout fl = flow_layout(D, S, L, U);
     const int64_t img_floats = mfma_image_floats(D, L);
     const int nl = 2 * S;
@@ -829,7 +832,10 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
         a.fold_stride = (int64_t)nl * 2 * D;
         a.g_lp = (c == 0) ? g_log_prob : nullptr;
         a.glp_sum = glp_sum;
-        rc = launch_coupling_backward_mfma_args(a, D, L, 1, st);
+        a.gmax = gmaxw;
+        // split-f16 layer backward unless asked otherwise or it would spill (L = 3 without a spare unit)
+        if (g_train_bwd_fp32 || (L == 3 && U > 15)) rc = launch_coupling_backward_mfma_args(a, D, L, 1, st);
+        else rc = launch_coupling_backward_f16(a, D, L, 1, st);
         if (rc) return rc;
     }
     return launch_flow_fold_backward(params, bn_alpha, gfold, glp_sum, g_params, M_p, D, S, L, U, pstride, gpstride,

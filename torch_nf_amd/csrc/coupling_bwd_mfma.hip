@@ -523,7 +523,7 @@ int launch_coupling_backward_mfma(const float* z, const float* params, const flo
                                   int64_t gpstride, hipStream_t st) {
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "coupling_backward_mfma: D=%d L=%d U=%d", D, L, U);
     BwdArgs a{z, params, g_zout, g_ld, g_z, g_params, M, Mp, N, pstride, gpstride, U, upper,
-              nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, nullptr, nullptr};
+              nullptr, 0, nullptr, nullptr, 0, nullptr, 1.f, nullptr, nullptr, nullptr};
     return launch_coupling_backward_mfma_args(a, D, L, inverse, st);
 }
 

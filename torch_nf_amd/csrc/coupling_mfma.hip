@@ -673,7 +673,7 @@ fold_bwd_apply_kernel(const float* g_in, const float* __restrict__ v, const floa
 int64_t flow_forward_train_workspace(int64_t M, int64_t Mp, int64_t N, int D, int S, int L) {
     // forward: as flow_forward_batch.  backward: PQ (Mp, 2, D) | S (Mp) | kk (2 D) | images | 2 x g buffers (M, N, D)
     const int64_t fwd = flow_forward_batch_workspace(Mp, D, S, L);
-    const int64_t bwd = (((Mp * 2 * D + Mp + 2 * D) * 4 + 255) / 256) * 256 + Mp * 2 * S * mfma_image_floats(D, L) * 4 +
+    const int64_t bwd = (((Mp * 2 * D + Mp + 1 + 2 * D) * 4 + 255) / 256) * 256 + Mp * 2 * S * mfma_image_floats(D, L) * 4 +
                         2 * (((M * N * D * 4) + 255) / 256) * 256 + 256;
     return fwd > bwd ? fwd : bwd;
 }
@@ -733,8 +733,9 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
     char* wsb = reinterpret_cast<char*>(ws);
     float* PQ = reinterpret_cast<float*>(wsb);
     float* Ssum = PQ + Mp * 2 * D;
-    float* kk = Ssum + Mp;
-    const int64_t head = (((Mp * 2 * D + Mp + 2 * D) * 4 + 255) / 256) * 256;
+    unsigned* gmaxw = reinterpret_cast<unsigned*>(Ssum + Mp);  // max |upstream gradient|, for the split-f16 layer kernels
+    float* kk = Ssum + Mp + 1;
+    const int64_t head = (((Mp * 2 * D + Mp + 1 + 2 * D) * 4 + 255) / 256) * 256;
     float* images = reinterpret_cast<float*>(wsb + head);
     const int nl = 2 * S;
     const int64_t img_floats = mfma_image_floats(D, L), plane = M * N * D;
@@ -754,8 +755,12 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
     const int64_t rpb = (N + sb - 1) / sb;
     const double rows = (double)M * (double)N;
     // ---- the last fold (behind layer nl-1): sums over (g_z, v), then g_v ----
-    if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D + Mp) * sizeof(float), st) != hipSuccess)
+    if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D + Mp + 1) * sizeof(float), st) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_forward_train_bwd: memset failed");
+    rc = launch_gmax(g_z, M * N * D, gmaxw, st);
+    if (rc) return rc;
+    rc = launch_gmax(g_sld, M * N, gmaxw, st);
+    if (rc) return rc;
     const float* v_last = states + (int64_t)(nl - 1) * plane;
     hipLaunchKernelGGL(fold_sums_kernel, grid_xm(sb, M), dim3(256), (size_t)fs_rpi * 2 * D * sizeof(float), st, g_z, v_last,
                        g_sld, PQ, Ssum, Mp, N, D, rpb);
@@ -796,9 +801,10 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
         a.g_fold = c == 0 ? nullptr : PQ;
         a.fold_stride = 2 * (int64_t)D;
         a.gcorr = (c == nl - 1) ? nullptr : kk;
+        a.gmax = gmaxw;
         // split-f16 layer backward (flow_bwd_f16.hip) unless asked otherwise or it would spill (L = 3 without a spare unit)
         if (g_train_bwd_fp32 || (L == 3 && U > 15)) rc = launch_coupling_backward_mfma_args(a, D, L, 0, st);
-        else rc = launch_coupling_backward_f16(a, D, L, st);
+        else rc = launch_coupling_backward_f16(a, D, L, 0, st);
         if (rc) return rc;
         cur ^= 1;
     }

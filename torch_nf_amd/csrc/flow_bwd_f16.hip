@@ -173,7 +173,17 @@ __global__ void __launch_bounds__(256)
 flow_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ out) {
     __shared__ float red[4];
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(g) & 15) == 0 ? n >> 2 : 0;  // 16-byte part, four loads in flight
+    const f4* g4 = reinterpret_cast<const f4*>(g);
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * step) {
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i + u * step < n4) ? g4[i + u * step] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) m = fmaxf(m, fabsf(g[i]));
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -181,6 +191,15 @@ flow_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ 
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (m > 0.f) atomicMax(out, __float_as_uint(m));  // one atomic per block: they serialise on the one word
     }
+}
+
+int launch_gmax(const float* g, int64_t n, unsigned* out, hipStream_t st) {
+    if (n <= 0) return TNF_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, out);
+    return check_launch("gmax");
 }
 
 // acc layout (lane (s, q), reg j = row 4q + j, col s)  ->  operand layout with K = samples:
@@ -399,11 +418,13 @@ struct RegAccum {
 
 // SPARE (num_units <= 15): hidden unit 15 is padding, so the transposed activation operand carries a row of
 // ones there and the bias gradients of the layers behind a tanh arrive as column 15 of the weight-gradient tiles.
-// FWD = false: the inverse-pass layer of the whole-flow kernel (y comes in as the layer's OUTPUT and leaves as its
-// input).  FWD = true: a forward-direction layer y' = t + y e^s with its INPUT saved (y stays); kc, when not NULL,
+// MODE 0: the inverse-pass layer of the whole-flow kernel (y comes in as the layer's OUTPUT and leaves as its
+// input).  MODE 1: a forward-direction layer y' = t + y e^s with its INPUT saved (y stays); kc, when not NULL,
 // points at this lane's [k0 | k1] constants (k1 at kc + D) of the batch-moment correction for the transformed
-// half: the upstream gradient is g + k0 + k1 y'.
-template <int H, int L, bool SPARE, bool FWD, class ACCP>
+// half: the upstream gradient is g + k0 + k1 y'.  MODE 2: an inverse-direction layer y' = (y - t) e^-s with its
+// INPUT saved; kmask != 0 with kc == NULL means "finalize": the upstream gradient of the transformed half is
+// gl_fin * y' (the base density's -g_log_prob y'), passed in kmask.
+template <int H, int L, bool SPARE, int MODE, class ACCP>
 __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float* scrA, float* scrB, int lane, int U,
                                             const f4 (&x)[(H + 15) / 16], f4 (&y)[(H + 15) / 16],
                                             f4 (&gx)[(H + 15) / 16], f4 (&gy)[(H + 15) / 16], float gl,
@@ -498,7 +519,15 @@ __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float*
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float e = __builtin_amdgcn_exp2f(sv[j]);
-                if (FWD) {
+                if (MODE == 2) {
+                    const float em = __builtin_amdgcn_exp2f(-sv[j]);
+                    const float yo = (y[mo][j] - tt[j]) * em;
+                    const float g = gy[mo][j] + kmask * yo;
+                    const float dy = g * em;
+                    dout[0][mo][j] = -dy;
+                    dout[1][mo][j] = __builtin_fmaf(-g, yo, gl);
+                    gy[mo][j] = dy;
+                } else if (MODE == 1) {
                     float g = gy[mo][j];
                     if (kc) g += kmask * __builtin_fmaf(kc[2 * H + 16 * mo + j], __builtin_fmaf(y[mo][j], e, tt[j]), kc[16 * mo + j]);
                     const float dy = g * e;
@@ -725,12 +754,12 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
             const float* fc = img + R::C_OFF;
             if ((c & 1) == 0) {  // RealNVP(upper): conditioner = low half
                 LdsFxAccum<H, L> ap{acc, fa, s, q};
-                layer_bwd16<H, L, SPARE, false>(img, ap, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
+                layer_bwd16<H, L, SPARE, 0>(img, ap, scrA, scrB, lane, U, lo, hi, glo, ghi, gl);
                 unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
                 unfold_half<H, false>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             } else {             // RealNVP(lower) behind BatchNorm + Affine
                 LdsFxAccum<H, L> ap{acc, fa, s, q};
-                layer_bwd16<H, L, SPARE, false>(img, ap, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
+                layer_bwd16<H, L, SPARE, 0>(img, ap, scrA, scrB, lane, U, hi, lo, ghi, glo, gl);
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             }
@@ -810,7 +839,7 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
 // ---------------------------------------------------------------------------
 constexpr int kLayerNW = 8;
 
-template <int H, int L, bool SPARE>
+template <int H, int L, bool SPARE, bool INV>
 __global__ void __launch_bounds__(kLayerNW * 64)
 coupling_bwd_f16_kernel(BwdArgs a) {
     typedef RevImage<H, L> R;
@@ -832,17 +861,33 @@ coupling_bwd_f16_kernel(BwdArgs a) {
     float* scrA = lds + R::FLOATS + wave * kScr;
     if (wave == 0) build_f16_image<H, L>(img + R::F_OFF, prow, U, lane);
     if (wave == 1) build_b16_image<H, L>(img + R::B_OFF, prow, U, lane);
-    const bool has_corr = a.gcorr != nullptr;
+    const bool has_corr = !INV && a.gcorr != nullptr;
+    const bool finalize = INV && a.g_lp != nullptr;  // last layer of a log_prob chain: seeds from the base density
+    // the deltas are split into f16 halves: keep them clear of the f16 subnormals whatever the loss scale
+    float sc = 1.f, isc = 1.f;
+    if (a.gmax) {
+        const float gm = __uint_as_float(*a.gmax);
+        if (gm > 0.f && gm < 3.0e38f) {
+            int e;
+            (void)frexpf(gm, &e);
+            int k = 1 - e;
+            k = k > 120 ? 120 : (k < -120 ? -120 : k);
+            sc = ldexpf(1.f, k);
+            isc = ldexpf(1.f, -k);
+        }
+    }
     for (int i = threadIdx.x; i < 2 * D; i += NW * 64) {
         cst[i] = a.fold ? a.fold[mp * a.fold_stride + i] : (i < D ? 1.f : 0.f);
-        cst[2 * D + i] = has_corr ? a.gcorr[i] : 0.f;
+        cst[2 * D + i] = has_corr ? sc * a.gcorr[i] : 0.f;
     }
     __syncthreads();
 
     const int c_off = a.upper ? 0 : H, t_off = a.upper ? H : 0;
     const float* zb = a.z + m * a.N * D;
-    const float* gzo = a.g_zout + m * a.N * D;
+    const float* gzo = a.g_zout ? a.g_zout + m * a.N * D : nullptr;
     const float* gld = a.g_ld + m * a.N;
+    const float* glpb = finalize ? a.g_lp + m * a.N : nullptr;
+    float glp_acc = 0.f;
     float* gzb = a.g_z + m * a.N * D;
     const float* cx = cst + c_off + 4 * q;  // this lane's conditioner / transformed features
     const float* cy = cst + t_off + 4 * q;
@@ -872,15 +917,21 @@ coupling_bwd_f16_kernel(BwdArgs a) {
         int64_t nrow = (tile + tstep) * 16 + s;
         if (nrow >= a.N) nrow = a.N - 1;
         f4 xs[HT], ys[HT], x[HT], y[HT], gx[HT], gy[HT];
+        const float glp = (finalize && row_ok) ? sc * glpb[rowc] : 0.f;
+        if (q == 0) glp_acc += glp;
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
-            const float* gr = gzo + rowc * D + 4 * q + 16 * mm;
             xs[mm] = nxs[mm];
             ys[mm] = nys[mm];
             nxs[mm] = *reinterpret_cast<const f4*>(zb + nrow * D + 4 * q + 16 * mm + c_off);
             nys[mm] = *reinterpret_cast<const f4*>(zb + nrow * D + 4 * q + 16 * mm + t_off);
-            gx[mm] = row_ok ? *reinterpret_cast<const f4*>(gr + c_off) : zero;
-            gy[mm] = row_ok ? *reinterpret_cast<const f4*>(gr + t_off) : zero;
+            gx[mm] = zero;
+            gy[mm] = zero;
+            if (gzo && row_ok) {
+                const float* gr = gzo + rowc * D + 4 * q + 16 * mm;
+                gx[mm] = sc * *reinterpret_cast<const f4*>(gr + c_off);
+                gy[mm] = sc * *reinterpret_cast<const f4*>(gr + t_off);
+            }
             const f4 ax = *reinterpret_cast<const f4*>(cx + 16 * mm), bx = *reinterpret_cast<const f4*>(cx + D + 16 * mm);
             const f4 ay = *reinterpret_cast<const f4*>(cy + 16 * mm), by = *reinterpret_cast<const f4*>(cy + D + 16 * mm);
 #pragma unroll
@@ -889,9 +940,19 @@ coupling_bwd_f16_kernel(BwdArgs a) {
                 y[mm][j] = __builtin_fmaf(ys[mm][j], ay[j], by[j]);
             }
         }
-        const float gl = row_ok ? a.ld_scale * gld[rowc] : 0.f;
-        layer_bwd16<H, L, SPARE, true>(img, ra, scrA, scrA, lane, U, x, y, gx, gy, gl, has_corr ? cy + 2 * D : nullptr,
-                                       row_ok ? 1.f : 0.f);
+        const float gl = row_ok ? sc * a.ld_scale * gld[rowc] : 0.f;
+        if (INV) {
+            if (finalize) {  // d(-|out|^2 / 2)/d out . g_lp: the conditioner half of out is x itself
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gx[mm][j] = -glp * x[mm][j];
+            }
+            layer_bwd16<H, L, SPARE, 2>(img, ra, scrA, scrA, lane, U, x, y, gx, gy, gl, nullptr, finalize ? -glp : 0.f);
+        } else {
+            layer_bwd16<H, L, SPARE, 1>(img, ra, scrA, scrA, lane, U, x, y, gx, gy, gl, has_corr ? cy + 2 * D : nullptr,
+                                        row_ok ? 1.f : 0.f);
+        }
         if (has_corr && row_ok) {  // the conditioner half of the output is x itself; added here (the layer code is linear
                                    // in gx) so that the g loads stay in flight during the forward recompute
 #pragma unroll
@@ -911,8 +972,8 @@ coupling_bwd_f16_kernel(BwdArgs a) {
                 dBx[mm][j] += gx[mm][j];
                 dAy[mm][j] = __builtin_fmaf(gy[mm][j], ys[mm][j], dAy[mm][j]);
                 dBy[mm][j] += gy[mm][j];
-                gx[mm][j] *= ax[j];
-                gy[mm][j] *= ay[j];
+                gx[mm][j] *= ax[j] * isc;
+                gy[mm][j] *= ay[j] * isc;
             }
             if (row_ok) {
                 float* gr = gzb + row * D + 4 * q + 16 * mm;
@@ -974,23 +1035,33 @@ coupling_bwd_f16_kernel(BwdArgs a) {
         }
         __syncthreads();
     }
+    if (finalize && a.glp_sum) {
+        const float tot = red16(glp_acc);
+        if (lane == 0) atomicAdd(a.glp_sum + mp, tot * isc);
+    }
     const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
     float* gout = a.g_params + mp * a.gpstride;
-    for (int k = threadIdx.x; k < P; k += NW * 64) atomicAdd(gout + k, gacc[acc_src<H, L, SPARE>(k, U)]);
+    for (int k = threadIdx.x; k < P; k += NW * 64) atomicAdd(gout + k, gacc[acc_src<H, L, SPARE>(k, U)] * isc);
     if (a.g_fold) {
         float* gfo = a.g_fold + mp * a.fold_stride;
-        for (int i = threadIdx.x; i < 2 * D; i += NW * 64) atomicAdd(gfo + i, gacc[A_::o_fold + i]);
+        for (int i = threadIdx.x; i < 2 * D; i += NW * 64) atomicAdd(gfo + i, gacc[A_::o_fold + i] * isc);
     }
 }
 
 template <int H, int L>
-static void launch_layer_f16(const BwdArgs& a, dim3 grid, hipStream_t st) {
-    if (a.U <= 15) hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, true>), grid, dim3(kLayerNW * 64), 0, st, a);
-    else hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, false>), grid, dim3(kLayerNW * 64), 0, st, a);
+static void launch_layer_f16(const BwdArgs& a, int inverse, dim3 grid, hipStream_t st) {
+    const dim3 blk(kLayerNW * 64);
+    if (inverse) {
+        if (a.U <= 15) hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, true, true>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, false, true>), grid, blk, 0, st, a);
+    } else {
+        if (a.U <= 15) hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, true, false>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((coupling_bwd_f16_kernel<H, L, false, false>), grid, blk, 0, st, a);
+    }
 }
 
-// forward-direction layers only (inverse = 0); shapes of mfma_supported(); g_z_out, g_ld, g_z required
-int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, hipStream_t st) {
+// shapes of mfma_supported(); g_ld and g_z required; g_z_out may be NULL only when g_lp seeds the layer (finalize)
+int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, int inverse, hipStream_t st) {
     if (!(D == 64 || D == 32) || L < 1 || L > 3 || a.U < 1 || a.U > 16)
         return fail(TNF_EUNSUPPORTED, "coupling_backward_f16: D=%d L=%d U=%d", D, L, a.U);
     if (a.N <= 0) return TNF_OK;
@@ -1000,13 +1071,13 @@ int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, hipStream_t st)
     if (bx > cap) bx = cap;
     const dim3 grid = grid_xm(bx, a.M);
     if (D == 64) {
-        if (L == 1) launch_layer_f16<32, 1>(a, grid, st);
-        else if (L == 2) launch_layer_f16<32, 2>(a, grid, st);
-        else launch_layer_f16<32, 3>(a, grid, st);
+        if (L == 1) launch_layer_f16<32, 1>(a, inverse, grid, st);
+        else if (L == 2) launch_layer_f16<32, 2>(a, inverse, grid, st);
+        else launch_layer_f16<32, 3>(a, inverse, grid, st);
     } else {
-        if (L == 1) launch_layer_f16<16, 1>(a, grid, st);
-        else if (L == 2) launch_layer_f16<16, 2>(a, grid, st);
-        else launch_layer_f16<16, 3>(a, grid, st);
+        if (L == 1) launch_layer_f16<16, 1>(a, inverse, grid, st);
+        else if (L == 2) launch_layer_f16<16, 2>(a, inverse, grid, st);
+        else launch_layer_f16<16, 3>(a, inverse, grid, st);
     }
     return check_launch("coupling_backward_f16");
 }

@@ -183,11 +183,14 @@ struct BwdArgs {
     const float* g_lp;    // finalize: upstream gradient is that of log_prob = -|out|^2/2 - ... (M,N)
     float ld_scale;       // gradient w.r.t. sum(s) = ld_scale * g_ld[row]
     float* glp_sum;       // finalize: accumulates sum over the samples of g_lp (per mp), for the constant log-det
+    const unsigned* gmax; // split-f16 layer kernel only: float bits of max |upstream gradient| of the whole chain (or NULL):
+                          // the kernel works on gradients scaled by the power of two that brings it into [1, 2)
     const float* gcorr;   // [k0 (D) | k1 (D)] or NULL: the upstream gradient is g_zout + k0 + k1 * (this layer's output)
                           // (batch-statistics backward of the fold behind the layer, forward direction only)
 };
 int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);
-int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, hipStream_t st);  // forward direction, split-f16 (flow_bwd_f16.hip)
+int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);  // split-f16 (flow_bwd_f16.hip)
+int launch_gmax(const float* g, int64_t n, unsigned* out, hipStream_t st);  // atomicMax of |g| (float bits) into *out
 int launch_coupling_backward_mfma(const float* z, const float* params, const float* g_zout,
                                   const float* g_ld, float* g_z, float* g_params, int64_t M, int64_t Mp,
                                   int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
