@@ -119,3 +119,34 @@ def test_widened_entries_host_side(oracle):
                                         64, 64, 64, ctypes.c_void_p(264), ws, None)
     assert rc == -1 and b"aligned" in lib.tnf_last_error()
     assert lib.tnf_set_option(_lib.OPT_COND_VARIANT, 0) == 0
+
+
+def test_training_entries_host_side():
+    """Support queries, workspace sizes and argument checks of the training entry points added after the metric
+    path (reversible pair, AR one-kernel backward, batch-statistics chains): host-only, no launches."""
+    from torch_nf_amd._lib import lib
+
+    # reversible pair: the 2S layers' gradient accumulators must fit the 160 KB LDS
+    assert lib.tnf_flow_train_rev_supported(64, 4, 2, 15) == 1 and lib.tnf_flow_train_rev_supported(32, 4, 3, 16) == 1
+    assert lib.tnf_flow_train_rev_supported(64, 5, 2, 15) == 0 and lib.tnf_flow_train_rev_supported(64, 4, 3, 15) == 0
+    assert lib.tnf_flow_train_rev_supported(8, 2, 2, 15) == 0 and lib.tnf_flow_train_rev_supported(64, 4, 2, 17) == 0
+    w1, w4 = lib.tnf_flow_train_rev_workspace_bytes(1, 64, 4, 2, 15), lib.tnf_flow_train_rev_workspace_bytes(4, 64, 4, 2, 15)
+    assert 0 < w1 < w4 and lib.tnf_flow_train_rev_workspace_bytes(1, 64, 5, 2, 15) < 0
+    # AR one-kernel backward: the MFMA MAF backward's shapes
+    assert lib.tnf_ar_flow_train_supported(6, 2, 15) == 1 and lib.tnf_ar_flow_train_supported(21, 2, 42) == 1
+    assert lib.tnf_ar_flow_train_supported(33, 2, 15) == 0 and lib.tnf_ar_flow_train_supported(6, 4, 15) == 0
+    assert lib.tnf_ar_flow_bwd_workspace_bytes(2000, 6) >= 2000 * (4 * 6 + 2) * 4
+    # batch-statistics chains
+    assert 0 < lib.tnf_flow_forward_batch_workspace_bytes(1, 64, 4, 2) < lib.tnf_flow_forward_batch_workspace_bytes(8, 64, 4, 2)
+    a = lib.tnf_flow_forward_train_workspace_bytes(1, 1, 1 << 16, 64, 4, 2)
+    assert a >= 2 * (1 << 16) * 64 * 4 and lib.tnf_flow_forward_train_workspace_bytes(2, 3, 10, 64, 4, 2) < 0
+    # argument checks come before any launch (NULL pointers, no GPU needed)
+    EINVAL, EUNSUP = -1, -2
+    n = None
+    assert lib.tnf_flow_log_prob_fwd_rev_f32(n, n, n, n, n, n, 1, 1, 16, 8, 2, 2, 15, 100000, n) == EUNSUP
+    assert lib.tnf_flow_log_prob_bwd_rev_f32(n, n, n, n, n, n, n, 2, 3, 16, 64, 4, 2, 15, 100000, 100000, n, 0, n) == EINVAL
+    assert lib.tnf_ar_flow_log_prob_bwd_f32(n, n, n, n, n, n, n, n, 1, 1, 16, 40, 2, 15, 100000, 100000, n, 0, n) == EUNSUP
+    assert lib.tnf_flow_forward_batch_f32(n, n, n, n, n, n, 1, 1, 1, 64, 4, 2, 15, 100000, 1e-5, n, 0, n) == EINVAL  # one row
+    assert lib.tnf_flow_forward_train_bwd_f32(n, n, n, n, n, n, n, n, n, n, 1, 1, 64, 8, 2, 2, 15, 100000, 100000, n, 0, n) == EUNSUP
+    assert lib.tnf_maf_inverse_alpha(7, n, n, n, n, n, n, 1, 1, 4, 3, 2, 15, 1000, n) == EINVAL  # dtype
+    assert b"dtype" in lib.tnf_last_error()
