@@ -607,34 +607,49 @@ fold_sums_kernel(const float* __restrict__ g, const float* __restrict__ v, const
     }
 }
 
-// one block: the backward of the fold behind layer c.  kk: [k0 (D) | k1 (D)]
+// the backward of the fold behind layer c, in two steps so that thousands of contexts do not queue up in one block:
+// (1) per (context, feature): the Affine gradients, and the contributions to g_r, g_mu and the sum of S_m into
+//     racc [g_r part (D) | g_mu part (D) | sum S (1)] (zeroed by the caller);  (2) one block: kk = [k0 (D) | k1 (D)]
 __global__ void __launch_bounds__(256)
-fold_backward_kernel(const float* __restrict__ params, int64_t pstride, int64_t affine_off, const float* __restrict__ mean,
-                     const float* __restrict__ alpha, const float* __restrict__ PQ, const float* __restrict__ Ssum,
-                     float* __restrict__ g_params, int64_t gpstride, float* __restrict__ kk, int64_t Mp, double rows,
-                     int D, int has_affine) {
-    for (int d = threadIdx.x; d < D; d += 256) {
-        const float mu = mean[d], r = 1.f / alpha[d];
-        double g_r = 0.0, g_mu = 0.0, s_all = 0.0;
-        for (int64_t m = 0; m < Mp; ++m) {
-            const float P = PQ[m * 2 * D + d], Q = PQ[m * 2 * D + D + d];
-            float e = 1.f;
-            if (has_affine) {
-                e = expf(params[m * pstride + affine_off + d]);
-                atomicAdd(g_params + m * gpstride + affine_off + d, e * r * (P - mu * Q) + Ssum[m]);
-                atomicAdd(g_params + m * gpstride + affine_off + D + d, Q);
-            }
-            g_r += (double)e * ((double)P - (double)mu * (double)Q);
-            g_mu -= (double)e * (double)Q;
-            s_all += (double)Ssum[m];
-        }
-        // (with one shared parameter row, PQ[0] and Ssum[0] already hold the sums over all M sample batches)
-        g_r += s_all / (double)r;
-        g_mu *= (double)r;
-        const double k1 = -g_r * (double)r * (double)r * (double)r / rows;
-        kk[D + d] = (float)k1;
-        kk[d] = (float)(g_mu / rows - k1 * (double)mu);
+fold_backward_ctx_kernel(const float* __restrict__ params, int64_t pstride, int64_t affine_off, const float* __restrict__ mean,
+                         const float* __restrict__ alpha, float* __restrict__ PQ, const float* __restrict__ Ssum,
+                         float* __restrict__ g_params, int64_t gpstride, float* __restrict__ racc, int64_t Mp, int D,
+                         int has_affine) {
+    const int per = 256 / D > 0 ? 256 / D : 1;  // contexts per block (D <= 256)
+    const int ml = threadIdx.x / D, d = threadIdx.x - ml * D;
+    const int64_t m = (int64_t)blockIdx.x * per + ml;
+    if (ml >= per || m >= Mp) return;
+    const float mu = mean[d], r = 1.f / alpha[d];
+    const float P = PQ[m * 2 * D + d], Q = PQ[m * 2 * D + D + d];
+    PQ[m * 2 * D + d] = 0.f;  // consumed: ready for the next layer's sums (saves a memset per layer)
+    PQ[m * 2 * D + D + d] = 0.f;
+    float e = 1.f;
+    if (has_affine) {
+        e = expf(params[m * pstride + affine_off + d]);
+        atomicAdd(g_params + m * gpstride + affine_off + d, e * r * (P - mu * Q) + Ssum[m]);
+        atomicAdd(g_params + m * gpstride + affine_off + D + d, Q);
     }
+    atomicAdd(racc + d, e * (P - mu * Q));
+    atomicAdd(racc + D + d, -e * Q);
+    if (d == 0) atomicAdd(racc + 2 * D, Ssum[m]);
+}
+
+__global__ void __launch_bounds__(256)
+fold_backward_fin_kernel(const float* __restrict__ mean, const float* __restrict__ alpha, float* __restrict__ racc,
+                         float* __restrict__ kk, double rows, int D) {
+    const double s_all = (double)racc[2 * D];
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const double mu = mean[d], r = 1.0 / (double)alpha[d];
+        const double g_r = (double)racc[d] + s_all / r;  // sum_log_det carries -log alpha = log r
+        const double g_mu = (double)racc[D + d] * r;
+        racc[d] = 0.f;  // consumed: zero for the next layer
+        racc[D + d] = 0.f;
+        const double k1 = -g_r * r * r * r / rows;
+        kk[D + d] = (float)k1;
+        kk[d] = (float)(g_mu / rows - k1 * mu);
+    }
+    if (threadIdx.x == 0) racc[2 * D] = 0.f;
 }
 
 // g_out = g_in A[m] + k0 + k1 v   (fold == NULL: A = 1);  g_out may alias g_in
@@ -673,7 +688,7 @@ fold_bwd_apply_kernel(const float* g_in, const float* __restrict__ v, const floa
 int64_t flow_forward_train_workspace(int64_t M, int64_t Mp, int64_t N, int D, int S, int L) {
     // forward: as flow_forward_batch.  backward: PQ (Mp, 2, D) | S (Mp) | kk (2 D) | images | 2 x g buffers (M, N, D)
     const int64_t fwd = flow_forward_batch_workspace(Mp, D, S, L);
-    const int64_t bwd = (((Mp * 2 * D + Mp + 1 + 2 * D) * 4 + 255) / 256) * 256 + Mp * 2 * S * mfma_image_floats(D, L) * 4 +
+    const int64_t bwd = (((Mp * 2 * D + Mp + 1 + 4 * D + 1) * 4 + 255) / 256) * 256 + Mp * 2 * S * mfma_image_floats(D, L) * 4 +
                         2 * (((M * N * D * 4) + 255) / 256) * 256 + 256;
     return fwd > bwd ? fwd : bwd;
 }
@@ -734,8 +749,9 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
     float* PQ = reinterpret_cast<float*>(wsb);
     float* Ssum = PQ + Mp * 2 * D;
     unsigned* gmaxw = reinterpret_cast<unsigned*>(Ssum + Mp);  // max |upstream gradient|, for the split-f16 layer kernels
-    float* kk = Ssum + Mp + 1;
-    const int64_t head = (((Mp * 2 * D + Mp + 1 + 2 * D) * 4 + 255) / 256) * 256;
+    float* racc = Ssum + Mp + 1;  // [g_r part (D) | g_mu part (D) | sum S (1)]
+    float* kk = racc + 2 * D + 1;
+    const int64_t head = (((Mp * 2 * D + Mp + 1 + 4 * D + 1) * 4 + 255) / 256) * 256;
     float* images = reinterpret_cast<float*>(wsb + head);
     const int nl = 2 * S;
     const int64_t img_floats = mfma_image_floats(D, L), plane = M * N * D;
@@ -755,7 +771,7 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
     const int64_t rpb = (N + sb - 1) / sb;
     const double rows = (double)M * (double)N;
     // ---- the last fold (behind layer nl-1): sums over (g_z, v), then g_v ----
-    if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D + Mp + 1) * sizeof(float), st) != hipSuccess)
+    if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D + Mp + 1 + 2 * D + 1) * sizeof(float), st) != hipSuccess)  // .. racc
         return fail(TNF_ELAUNCH, "flow_forward_train_bwd: memset failed");
     rc = launch_gmax(g_z, M * N * D, gmaxw, st);
     if (rc) return rc;
@@ -769,8 +785,12 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
         // fold behind layer c: PQ holds its sums (from fold_sums for the last one, else from the layer c+1 backward)
         const float* g_in = (c == nl - 1) ? g_z : gbuf[cur];
         const int64_t aff = (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low;
-        hipLaunchKernelGGL(fold_backward_kernel, dim3(1), dim3(256), 0, st, params, pstride, aff, bn_mean + (int64_t)c * D,
-                           bn_alpha + (int64_t)c * D, PQ, Ssum, g_params, gpstride, kk, Mp, rows, D, c & 1);
+        const int per = 256 / D > 0 ? 256 / D : 1;
+        hipLaunchKernelGGL(fold_backward_ctx_kernel, dim3((unsigned)((Mp + per - 1) / per)), dim3(256), 0, st, params, pstride,
+                           aff, bn_mean + (int64_t)c * D, bn_alpha + (int64_t)c * D, PQ, Ssum, g_params, gpstride, racc, Mp, D,
+                           c & 1);
+        hipLaunchKernelGGL(fold_backward_fin_kernel, dim3(1), dim3(256), 0, st, bn_mean + (int64_t)c * D,
+                           bn_alpha + (int64_t)c * D, racc, kk, rows, D);
         // g wrt v_c = g_x A + k0 + k1 v_c.  The last fold applies it in a pass of its own (A included); for the inner
         // ones the coupling backward of the layer behind already multiplied by A, and k0 + k1 v_c is added by the
         // coupling backward kernel of layer c itself in its load stage (v_c is that layer's output).
@@ -779,9 +799,7 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
                                folds + (int64_t)c * Mp * 2 * D, kk, gbuf[cur ^ 1], Mp, N, D);
             cur ^= 1;
         }
-        // coupling layer c
-        if (hipMemsetAsync(PQ, 0, (size_t)(Mp * 2 * D) * sizeof(float), st) != hipSuccess)
-            return fail(TNF_ELAUNCH, "flow_forward_train_bwd: memset failed");
+        // coupling layer c (PQ was zeroed by fold_backward_ctx_kernel when it consumed it)
         BwdArgs a;
         memset(&a, 0, sizeof(a));
         const int64_t poff = (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
