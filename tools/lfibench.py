@@ -74,6 +74,9 @@ def run(d=3, M=2000, atoms=100):
         cde(x[:1], N=M * N, freeze_bn=True)
     ts = timeit(lambda: cde(x[:1], N=M * N, freeze_bn=True), 5)
     print("GPU: posterior sampling cde(x0, N=%d) %.3f ms (%.1f M samples/s)" % (M * N, ts * 1e3, M * N / ts / 1e6))
+    td = timeit(lambda: cde.sample(x[:1], N=M * N), 5)
+    print("GPU: posterior sampling cde.sample(x0, N=%d), device-side draw: %.3f ms (%.1f M samples/s)"
+          % (M * N, td * 1e3, M * N / td / 1e6))
     return dict(D=D, M=M, N=N, lb=lb, ub=ub, nf=nf, cde=cde, x=x, z=z, train_s=tt, infer_s=ti)
 
 

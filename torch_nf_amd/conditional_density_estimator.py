@@ -99,6 +99,13 @@ class ConditionalDensityEstimator(torch.nn.Module):
         params = self._params_for(x)
         return self.density_estimator(N=N, params=params, freeze_bn=freeze_bn)
 
+    def sample(self, x, N=100, freeze_bn=True, generator=None):
+        """Extension (not in the reference): like `__call__`, but the base draw comes from the device RNG
+        (`NormFlow.sample`), so posterior sampling is not bound by `np.random.normal` and the PCIe copy
+        (2*10^5 draws at D=6: 13 ms through `cde(x0, N)`, 0.3 ms here).  Not reproducible against np.random.seed."""
+        params = self._params_for(x)
+        return self.density_estimator.sample(N, params, freeze_bn=freeze_bn, generator=generator)
+
     def _fused_conditioner_ok(self, z, x):
         """One sample per context (the SNPE layout z[:, None, :]) on a coupling flow: the last Linear
         of param_net runs inside the flow kernel (tnf_cond_flow_log_prob_f32) and the (M, D_params)

@@ -59,8 +59,8 @@ def train_APT(cde, system, x0, M=1000, M_atom=100, R=4, num_iters=1000, lr=1e-3,
         if r == 0:
             z_new = system.sample_prior(num_sims)
         else:
-            with torch.no_grad():
-                z_s, _ = cde(x0_t, N=num_sims)
+            with torch.no_grad():  # proposals from the current posterior: device-side draw on a HIP device
+                z_s, _ = cde.sample(x0_t, N=num_sims) if dev.type == "cuda" else cde(x0_t, N=num_sims, freeze_bn=True)
             z_new = z_s[0].detach().cpu().numpy().astype(np.float64)
         x_new = system.simulate(z_new)
         ok = np.isfinite(x_new).all(1) & np.isfinite(system.log_prior(z_new))
