@@ -341,3 +341,36 @@ def test_layer_chains_keep_precision_at_any_loss_scale(tnf, oracle, scale):
     ((lqr.mean() + (zr ** 2).mean()) * scale).backward()
     sp = float((pr.grad / scale).abs().max())
     torch.testing.assert_close(p.grad.cpu() / scale, pr.grad / scale, rtol=5e-3, atol=2e-4 * sp)
+
+
+def test_training_step_full_size_properties(tnf):
+    """BASELINE cfg 4 at its full per-GPU size (2^19 samples, D=64, 8 coupling layers), where the oracle is too slow
+    to be the checker: (1) the reversible split-f16 pair, the per-layer split-f16 pair and the per-layer fp32-MFMA
+    pair -- three independent backward implementations -- agree on the gradient of -mean(log_prob); (2) linearity:
+    scaling the loss by 2^-10 * 0.37 scales the gradient by exactly that up to rounding (the kernels rescale the
+    upstream gradient by a power of two internally)."""
+    D, S, L, U, N = 64, 4, 2, 15, 1 << 19
+    rng = np.random.RandomState(0)
+    nf = tnf.NormFlow(D, False, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0.0, 0.1, (1, nf.D_params))).float().cuda()
+    for b in nf._bn_layers():
+        b.set_last_stats(torch.tensor(rng.normal(0, 0.3, D)).float(), torch.tensor(np.exp(rng.normal(0, 0.2, D))).float())
+    z = torch.randn(1, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+
+    def grad(reversible, fp32, scale=1.0):
+        tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, fp32))
+        try:
+            nf.reversible_training = reversible
+            nf.params = p0.clone().requires_grad_()
+            (-nf.log_prob(z).mean() * scale).backward()
+            return nf.params.grad.clone()
+        finally:
+            tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, 0)
+
+    g_rev, g_l16, g_l32 = grad(True, 0), grad(False, 0), grad(False, 1)
+    top = float(g_l32.abs().max())
+    assert top > 1e-3 and bool(torch.isfinite(g_rev).all())
+    assert float((g_rev - g_l32).abs().max()) <= 2e-5 * top
+    assert float((g_l16 - g_l32).abs().max()) <= 2e-5 * top
+    a = 0.37 / 1024.0
+    assert float((grad(True, 0, a) / a - g_rev).abs().max()) <= 2e-5 * top
