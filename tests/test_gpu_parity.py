@@ -452,3 +452,27 @@ def test_batch_stats_forward_one_call_vs_per_bijector(tnf, D, S, L, M, N):
     with torch.no_grad():
         lp = nf.log_prob(out[True][0], params)
     torch.testing.assert_close(lp.double(), out[True][1], rtol=1e-5, atol=2e-3)
+
+
+def test_batch_stats_forward_full_size_round_trip(tnf):
+    """Sampling with fresh batch statistics at 2^19 samples (D=64, 8 coupling layers), where the oracle is too slow:
+    the density the one-call chain reports for its samples is the density log_prob assigns to them afterwards (the
+    reference's own forward -> log_prob check, tests/test_density_estimators.py:147-245), the cached statistics are
+    those of a unit-variance, zero-mean batch behind every BatchNorm, and the one-node autograd pair returns the same
+    samples."""
+    D, S, L, U, N = 64, 4, 2, 15, 1 << 19
+    rng = np.random.RandomState(3)
+    nf = tnf.NormFlow(D, False, "coupling", S, L, U)
+    nf.params = torch.tensor(rng.normal(0.0, 0.1, (1, nf.D_params))).float().cuda()
+    omega = torch.randn(1, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    with torch.no_grad():
+        z, lq = nf._forward_from(omega, nf.params, freeze_bn=False)
+        lp = nf.log_prob(z)
+    assert bool(torch.isfinite(z).all()) and lq.dtype == torch.float64
+    torch.testing.assert_close(lp.double(), lq, rtol=1e-5, atol=5e-3)
+    alphas = torch.stack([b.get_last_alpha() for b in nf._bn_layers()])
+    assert bool((alphas > 0).all()) and alphas.shape == (2 * S, D)
+    p = nf.params.clone().requires_grad_()
+    z2, lq2 = nf._forward_from(omega, p, freeze_bn=False)
+    torch.testing.assert_close(z2.detach(), z, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lq2.detach(), lq, rtol=1e-6, atol=1e-3)
