@@ -17,7 +17,12 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
                    reference in the build container) timed on this box's host cores;
   layer_chain   -- the same call with one fused kernel per coupling layer (k = 8, the
                    HBM-bound design), measured after the timed region, with its own roofline;
-  parity        -- max relative error of the GPU log_prob vs the oracle on 2^16 samples.
+  parity        -- max relative error of the GPU log_prob vs the oracle on 2^16 samples;
+  train_step    -- BASELINE configs[3] per GPU: -mean(log_prob) on 2^19 samples, backward (reversible pair), Adam
+                   (with N GPUs: + the RCCL all-reduce of the flat gradient), outside the timed region;
+  widened       -- (1 GPU) the SURVEY 8f rows: fused conditional flow, AR log_prob, the LFI step as a HIP graph,
+                   sampling with fresh batch statistics under autograd.
+--no-extras skips train_step and widened (a clean per-kernel average under rocprofv3 --stats).
 """
 import argparse
 import json
