@@ -3,7 +3,12 @@
 (num_stages=4, L=2, U=15), N=2^20 samples per GPU, float32, inputs resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 runs one process per GPU over RCCL (torch.distributed backend "nccl").  Either launch it under
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment, as the driver does) or just call
+`python bench.py --gpus N`: a parent that never touches the GPU then starts the N ranks itself through
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process
+(nothing is ever re-exec'ed) and exits with its code.
 
 A "step" is one NormFlow.log_prob call over one (1, 2^20, 64) batch through the C ABI
 (tnf_flow_log_prob_f32).  The path shards over samples with no data-path collective, so
@@ -14,24 +19,30 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
   roofline      -- the dominant kernel of the timed path, from HIP events recorded on the
                    stream the kernels run on, inside the timed region;
   cpu_baseline  -- the PyTorch-CPU oracle (oracle/flow_oracle.py, verified equal to the
-                   reference in the build container) timed on this box's host cores;
+                   reference in the build container) timed on this box's host cores (os.cpu_count() threads;
+                   `threads16` = the same at 16 threads);
   layer_chain   -- the same call with one fused kernel per coupling layer (k = 8, the
-                   HBM-bound design), measured after the timed region, with its own roofline;
-  parity        -- max relative error of the GPU log_prob vs the oracle on 2^16 samples;
+                   HBM-bound design of north_star), measured after the timed region, with its own roofline;
+  parity        -- max relative error of the GPU log_prob vs the oracle on 2^16 samples (ENFORCED: exit code 1
+                   when it exceeds the tolerance);
+  rccl_ranks    -- sum over ranks of 1 through an RCCL all-reduce (proves N ranks took part);
+  strong_scaling-- the same call with N = 2^20 samples IN TOTAL split over the ranks (north_star quotes both);
   train_step    -- BASELINE configs[3] per GPU: -mean(log_prob) on 2^19 samples, backward (reversible pair), Adam
                    (with N GPUs: + the RCCL all-reduce of the flat gradient), outside the timed region;
+  configs       -- (1 GPU) BASELINE configs[1] (D = 32, own roofline) and configs[2] (ConditionalDensityEstimator,
+                   (M, N) = (16, 2^16): frozen forward + log_prob);
   widened       -- (1 GPU) the SURVEY 8f rows: fused conditional flow, AR log_prob, the LFI step as a HIP graph,
                    sampling with fresh batch statistics under autograd.
---no-extras skips train_step and widened (a clean per-kernel average under rocprofv3 --stats).
+--no-extras skips train_step, configs and widened (a clean per-kernel average under rocprofv3 --stats).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -42,6 +53,56 @@ F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
 
 D, S, L, U = 64, 4, 2, 15
 N_PER_GPU = 1 << 20
+PARITY_TOL = 1e-5
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline path only: skip the training step, the configs rows and the widened rows (keeps a "
+                         "rocprofv3 --stats average of the headline kernel free of their smaller launches)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = os.cpu_count()")
+    ap.add_argument("--dry-run-launcher", action="store_true",
+                    help="print the command the self-launcher would run for --gpus N and exit (no GPU, no children)")
+    return ap.parse_args()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(args, port=None):
+    """The child command `python bench.py --gpus N` starts when it is not already one rank of N."""
+    port = port or _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_extras:
+        cmd.append("--no-extras")
+    if args.cpu_threads:
+        cmd += ["--cpu-threads", str(args.cpu_threads)]
+    return cmd
+
+
+def self_launch(args):
+    """Parent of a plain `python bench.py --gpus N` (N > 1): it has made no GPU call (torch is not even imported
+    yet) and starts the ranks as a child process group; rank 0's JSON line reaches stdout through the child."""
+    cmd = launcher_command(args)
+    if args.dry_run_launcher:
+        print(json.dumps({"launcher": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def flop_per_sample(D, S, L, U):
@@ -55,184 +116,123 @@ def bytes_per_sample_chain(D, k):
     return 4 * D * (2 * k - 1) + 8 * (k - 1) + 4
 
 
-def build_model(tnf, dev):
-    """NormFlow(64, False, 'coupling', 4, 2, 15) with xavier_normal_ params (seed 0) and BatchNorm
-    statistics populated by one 4,096-sample batch-mode forward."""
-    torch.manual_seed(0)
-    np.random.seed(0)
-    nf = tnf.NormFlow(D, False, "coupling", S, L, U, device=dev)
-    with torch.no_grad():
-        nf(4096)  # batch-statistics forward on the GPU; caches mean/alpha in every BatchNorm
-    return nf
+def kernel_source_hash():
+    """Hash of the kernel sources: a PMC summary under profiles/ is only quoted for the code it was collected on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "torch_nf_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(nf, threads):
-    """Time the oracle on the host: same model, same synthetic z (generator seed 1)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import flow_oracle as orc
+def read_traffic(kernel_key):
+    """HBM bytes per launch from the newest committed PMC summary whose `kernel_source_sha16` equals the hash of the
+    kernel sources in this tree; None (and the reason) otherwise -- a stale counter is not a measurement."""
+    prof = os.path.join(ROOT, "profiles")
+    cur = kernel_source_hash()
+    cands = sorted((f for f in os.listdir(prof) if f.endswith("pmc.json")), reverse=True) if os.path.isdir(prof) else []
+    for name in cands:
+        try:
+            with open(os.path.join(prof, name)) as f:
+                js = json.load(f)
+        except Exception:
+            continue
+        if js.get("kernel_source_sha16") != cur or kernel_key not in js:
+            continue
+        return js[kernel_key].get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "kernel_source_sha16": cur}
+    return None, {"file": None, "kernel_source_sha16": cur,
+                  "why_null": "no profiles/*pmc.json was collected on these kernel sources"}
 
+
+def _time_oracle(torch, orc, z, params, D, S, L, U, stats, threads, reps):
     torch.set_num_threads(threads)
-    params = nf.params.detach().cpu()
-    stats = [(b.get_last_mean().cpu(), b.get_last_alpha().cpu()) for b in nf._bn_layers()]
-    n = N_PER_GPU
-    z = torch.randn(1, n, D, generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
-        t0 = time.perf_counter()
         orc.flow_log_prob(z, params, D, S, L, U, stats)  # warm-up
-        warm = time.perf_counter() - t0
-        if warm > 20.0:  # keep the default run within minutes
-            n = 1 << 18
-            z = z[:, :n].contiguous()
         best = float("inf")
-        for _ in range(3):
+        for _ in range(reps):
             t0 = time.perf_counter()
             orc.flow_log_prob(z, params, D, S, L, U, stats)
             best = min(best, time.perf_counter() - t0)
-    return {
+    return best
+
+
+def cpu_baseline(nf, threads, D, S, L, U):
+    """Time the oracle on the host: same model, same kind of synthetic z (generator seed 1), a bounded sample of
+    2^19 samples (1 warm-up + best of 2 per thread count keeps the whole leg within ~20 s of CPU work)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import flow_oracle as orc
+    import torch
+
+    params = nf.params.detach().cpu()
+    stats = [(b.get_last_mean().cpu(), b.get_last_alpha().cpu()) for b in nf._bn_layers()]
+    n = 1 << 19
+    z = torch.randn(1, n, D, generator=torch.Generator().manual_seed(1))
+    best = _time_oracle(torch, orc, z, params, D, S, L, U, stats, threads, 2)
+    row = {
         "value": round(n / best / 1e6, 4),
         "unit": "M samples/s",
         "cores": threads,
         "kind": "port",
         "sample": "oracle/flow_oracle.py flow_log_prob (PyTorch CPU, fp32, no_grad) on z (1, %d, %d), "
-                  "1 warm-up + best of 3, %d torch threads" % (n, D, threads),
-    }, orc, params, stats
-
-
-def widened_rows(tnf):
-    """Single-GPU extras for the SURVEY 8f rows built after the metric path: not the
-    metric, a few seconds in total."""
-    def timeit(fn, reps):
-        for _ in range(2):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
-
-    res = {}
-    np.random.seed(0)
-    torch.manual_seed(0)
-    nf = tnf.NormFlow(64, True, "coupling", 4, 2, 15)
-    cde = tnf.ConditionalDensityEstimator(nf, 32, [64, 64])
-    M = 1 << 18
-    x = torch.randn(M, 32, device="cuda")
-    z = torch.randn(M, 1, 64, device="cuda")
-
-    def infer():
-        with torch.no_grad():
-            cde.log_prob(z, x)
-
-    def train():
-        cde.zero_grad()
-        (-cde.log_prob(z, x).mean()).backward()
-
-    t = timeit(infer, 5)
-    res["cond_flow_log_prob"] = {"contexts": M, "ms": round(t * 1e3, 3), "value": round(M / t / 1e6, 1),
-                                 "unit": "M contexts/s", "what": "cde.log_prob(z[:, None, :], x), D=64 S=4, param_net "
-                                 "[64,64]: last Linear fused into the flow kernel, params (M, 20464) never materialised"}
-    t = timeit(train, 3)
-    res["cond_flow_train_step"] = {"contexts": M, "ms": round(t * 1e3, 3), "value": round(M / t / 1e6, 2),
-                                   "unit": "M contexts/s", "what": "forward + backward through param_net (fused pair)"}
-    del x, z, cde, nf
-    nf = tnf.NormFlow(16, False, "AR", 1, 2, 32)
-    z = torch.randn(1, 1 << 20, 16, device="cuda")
-    with torch.no_grad():
-        nf(64)
-        t = timeit(lambda: nf.log_prob(z), 10)
-    res["ar_log_prob"] = {"samples": 1 << 20, "ms": round(t * 1e3, 3), "value": round((1 << 20) / t / 1e6, 1),
-                          "unit": "M samples/s", "what": "NormFlow(16, arch_type='AR', num_layers=2, num_units=32).log_prob, "
-                          "one matrix-pipe MAF kernel"}
-    del z, nf
-    # the LFI scripts' inner step (scripts/lfi_mat.py:23-57): AR flow + ToInterval through param_net [64,64]
-    D_l, M_l, N_l = 6, 2000, 100
-    lb, ub = -2.0 * np.ones(D_l), 2.0 * np.ones(D_l)
-    lb[::2] = -np.inf
-    nfl = tnf.NormFlow(D_l, True, "AR", 1, 2, 2 * D_l, tnf.ToInterval(D_l, lb, ub))
-    cdel = tnf.ConditionalDensityEstimator(nfl, 3, [64, 64])
-    xl = torch.randn(M_l, 3, device="cuda")
-    zl = torch.rand(M_l, N_l, D_l, device="cuda") * 3.0 - 1.5
-    optl = torch.optim.Adam(cdel.parameters(), lr=1e-3, capturable=True)
-
-    def lfi_step():
-        optl.zero_grad(set_to_none=True)
-        loss = -cdel.log_prob(zl, xl).mean()
-        loss.backward()
-        optl.step()
-        return loss.detach()
-
-    te = timeit(lfi_step, 10)
-    gs = tnf.graphs.GraphedStep(lfi_step, warmup=3)
-    tg = timeit(gs, 20)
-    res["lfi_train_step"] = {"samples": M_l * N_l, "ms": round(tg * 1e3, 3), "eager_ms": round(te * 1e3, 3),
-                             "value": round(M_l * N_l / tg / 1e6, 1), "unit": "M samples/s",
-                             "what": "AR flow (D=6) + ToInterval conditioned through param_net [64,64], 2000 contexts x 100 "
-                             "samples: loss, one-kernel AR backward, Adam; replayed as one HIP graph (eager_ms: eagerly)"}
-    del cdel, nfl, xl, zl, optl, gs
-    # sampling with fresh batch statistics under autograd (the reference's train_efn objective shape)
-    nfe = tnf.NormFlow(64, False, "coupling", 4, 2, 15)
-    nfe.params = (torch.randn(1, nfe.D_params, device="cuda") * 0.1).requires_grad_()
-    om = torch.randn(1, 1 << 19, 64, device="cuda")
-
-    def efn():
-        nfe.params.grad = None
-        ze, lqe = nfe._forward_from(om, nfe.params, freeze_bn=False)
-        (lqe.mean() + (ze ** 2).mean()).backward()
-
-    t = timeit(efn, 5)
-    res["forward_train_step"] = {"samples": 1 << 19, "ms": round(t * 1e3, 3), "value": round((1 << 19) / t / 1e6, 1),
-                                 "unit": "M samples/s", "what": "z, log_q = nf(N) with fresh batch statistics, D=64 S=4; "
-                                 "backward through the batch moments (one autograd node, tnf_flow_forward_train_*)"}
-    return res
-
-
-def event_ms(pairs):
-    return [a.elapsed_time(b) for a, b in pairs]
-
-
-def read_traffic(kernel_key):
-    """HBM bytes per launch from the committed PMC summary (profiles/*_pmc.json), if any."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    try:
-        with open(path) as f:
-            return json.load(f)[kernel_key]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+                  "1 warm-up + best of 2, %d torch threads (os.cpu_count() = %d)" % (n, D, threads, os.cpu_count() or 1),
+    }
+    if threads > 16:
+        b16 = _time_oracle(torch, orc, z, params, D, S, L, U, stats, 16, 2)
+        row["threads16"] = {"value": round(n / b16 / 1e6, 4), "cores": 16}
+        torch.set_num_threads(threads)
+    return row, orc, params, stats
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="headline path only: skip the training step and the widened rows (keeps a rocprofv3 "
-                         "--stats average of the headline kernel free of their smaller launches)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), 16)")
-    args = ap.parse_args()
-
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run_launcher or (world == 1 and args.gpus > 1):
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+    # rehearsal of the N > 1 control flow on a one-GPU box: TNF_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses
+    # gloo (RCCL refuses two ranks on one device); the line then says so and is not a scaling measurement
+    rehearse = os.environ.get("TNF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
 
     import torch_nf_amd as tnf
 
     L_ = tnf._lib
-    nf = build_model(tnf, dev)
+
+    def build_model(D_):
+        """NormFlow(D, False, 'coupling', 4, 2, 15) with xavier_normal_ params (seed 0) and BatchNorm
+        statistics populated by one 4,096-sample batch-mode forward."""
+        torch.manual_seed(0)
+        np.random.seed(0)
+        nf_ = tnf.NormFlow(D_, False, "coupling", S, L, U, device=dev)
+        with torch.no_grad():
+            nf_(4096)  # batch-statistics forward on the GPU; caches mean/alpha in every BatchNorm
+        return nf_
+
+    nf = build_model(D)
     if world > 1:  # identical model everywhere: rank 0's parameters and BatchNorm statistics
         dist.broadcast(nf.params.data, 0)
         for b in nf._bn_layers():
@@ -249,38 +249,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(fusion, steps, warmup):
-        nf.fusion = fusion
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run(model, zz, fusion, steps, warmup):
+        model.fusion = fusion
         with torch.no_grad():
             for _ in range(warmup):
-                nf.log_prob(z)
+                model.log_prob(zz)
             pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                      for _ in range(steps)]
             barrier()
             t0 = time.perf_counter()
             for a, b in pairs:
                 a.record()
-                out = nf.log_prob(z)
+                out = model.log_prob(zz)
                 b.record()
             barrier()
             wall = time.perf_counter() - t0
-        return wall, event_ms(pairs), out
+        model.fusion = L_.FUSE_AUTO
+        return wall, [a.elapsed_time(b) for a, b in pairs], out
 
     fused = bool(L_.lib.tnf_flow_fused_supported(D, S, L, U))
     main_fusion = L_.FUSE_FLOW if fused else L_.FUSE_LAYER
-    wall, ev, lp = run(main_fusion, args.steps, args.warmup)
-    wall_t = torch.tensor([wall], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall_max = float(wall_t.item())
+    wall, ev, lp = run(nf, z, main_fusion, args.steps, args.warmup)
+    wall_max = max_over_ranks(wall)
 
     # the per-layer chain (k = 8), outside the timed region
-    wall_l, ev_l, lp_l = run(L_.FUSE_LAYER, max(5, args.steps // 2), 2)
+    wall_l, ev_l, lp_l = run(nf, z, L_.FUSE_LAYER, max(5, args.steps // 2), 2)
+
+    # strong scaling: 2^20 samples in total, split over the ranks (north_star: "N=2^20 ... at 1, 2, 4 and 8 GPUs")
+    strong = None
+    if world > 1:
+        from torch_nf_amd.distributed import shard_bounds
+
+        lo, hi = shard_bounds(N_PER_GPU, world, rank)
+        z_s = z[:, :hi - lo].contiguous()
+        wall_s, _, _ = run(nf, z_s, main_fusion, args.steps, args.warmup)
+        wall_s = max_over_ranks(wall_s)
+        strong = {"samples_total": N_PER_GPU, "samples_per_gpu": hi - lo, "ms_per_step": round(wall_s / args.steps * 1e3, 4),
+                  "value": round(N_PER_GPU * args.steps / wall_s / 1e6, 2), "unit": "M samples/s", "scaling": "strong"}
 
     # BASELINE configs[3], per-GPU share: one training step (loss = -mean log_prob, backward, Adam)
     # on 2^19 samples; outside the timed region.  With N GPUs the only collective is the gradient.
     train_ms = None
-    if (rank == 0 or world > 1) and not args.no_extras:
+    if not args.no_extras:
         n_tr = 1 << 19
         p_train = nf.params.detach().clone().requires_grad_()
         nf_params_saved, nf.params = nf.params, p_train
@@ -298,12 +314,12 @@ def main():
 
         for _ in range(2):
             train_step()
-        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(5):
             train_step()
-        torch.cuda.synchronize()
-        train_ms = (time.perf_counter() - t0) / 5 * 1e3
+        barrier()
+        train_ms = max_over_ranks(time.perf_counter() - t0) / 5 * 1e3
         nf.params = nf_params_saved
 
     if rank != 0:
@@ -311,47 +327,55 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_samples = N_PER_GPU * world * args.steps
-    value = total_samples / wall_max / 1e6
-    flops = flop_per_sample(D, S, L, U)
-    ev_mean = float(np.mean(ev))  # ms per call on the launch stream = the one kernel of the call (it builds its operands in its prologue)
-    if fused:
-        achieved = N_PER_GPU * flops / (ev_mean * 1e-3) / 1e12
+    def fused_roofline(D_, ev_mean, n, kernel):
+        flops = flop_per_sample(D_, S, L, U)
+        achieved = n * flops / (ev_mean * 1e-3) / 1e12
         # Matrix-pipe roof of THIS formulation: every fp32-accurate product is three f16 MFMA products
         # (hi*hi + lo*hi + hi*lo, fp32 accumulate), so the ceiling for algorithmic fp32 flops is the dense
         # f16 MFMA peak / 3.  (The kernel is not bound by it: sigmoids/exps and the operand splitting on the
         # vector pipe are -- DESIGN.md 3.4; the dense fp32 MFMA peak, 157.3 TFLOP/s, is already exceeded.)
         split_peak = F16_MFMA_TFLOPS / 3.0
-        roofline = {"bound": "mfma", "kernel": "flow_fused_f16_kernel<32,2,inverse,2,8,4>", "achieved": round(achieved, 3),
-                    "peak": round(split_peak, 1), "unit": "TFLOP/s", "frac": round(achieved / split_peak, 4),
-                    "traffic": read_traffic("flow_fused_f16_kernel"),
-                    "note": "achieved = algorithmic fp32 flops (42,176 per sample) / launch time; peak = dense f16 MFMA "
+        traffic, stamp = read_traffic("flow_fused_f16_kernel") if D_ == 64 else (None, None)
+        r = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3), "peak": round(split_peak, 1),
+             "unit": "TFLOP/s", "frac": round(achieved / split_peak, 4), "traffic": traffic,
+             "algorithmic_flop_per_sample": flops, "launch_ms": round(ev_mean, 4),
+             "fp32_mfma_peak_tflops": F32_MFMA_TFLOPS, "frac_of_fp32_mfma_peak": round(achieved / F32_MFMA_TFLOPS, 4),
+             "hbm_compulsory_frac": round(n * bytes_per_sample_chain(D_, 1) / (ev_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if stamp is not None:
+            r["traffic_source"] = stamp
+        return r
+
+    def chain_roofline(D_, evl_mean, n, kernel):
+        k = 2 * S
+        gbs = n * bytes_per_sample_chain(D_, k) / (evl_mean * 1e-3) / 1e9
+        traffic, stamp = read_traffic("coupling_mfma_kernel") if D_ == 64 else (None, None)
+        r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+             "algorithmic_bytes_per_sample_all_launches": bytes_per_sample_chain(D_, k)}
+        if stamp is not None:
+            r["traffic_source"] = stamp
+        return r
+
+    total_samples = N_PER_GPU * world * args.steps
+    value = total_samples / wall_max / 1e6
+    ev_mean = float(np.mean(ev))  # ms per call on the launch stream = the one kernel of the call (it builds its operands in its prologue)
+    roofline = None
+    if fused:
+        roofline = fused_roofline(D, ev_mean, N_PER_GPU, "flow_fused_f16_kernel<32,2,inverse,2,8,4>")
+        roofline["note"] = ("achieved = algorithmic fp32 flops (42,176 per sample) / launch time; peak = dense f16 MFMA "
                             "peak (2,500 TFLOP/s) / 3, because each fp32-accurate contraction is issued as 3 split-f16 "
                             "MFMAs with fp32 accumulate; the binding unit is the vector pipe (sigmoids/exps + operand "
-                            "splitting), not the matrix pipe or HBM",
-                    "algorithmic_flop_per_sample": flops, "launch_ms": round(ev_mean, 4),
-                    # what the matrix pipe itself sees: 24 f16 MFMAs per 16 samples and layer
-                    # (6 x 16x16x32 + 18 x 16x16x16) = 15,360 flop/sample/layer, against 2.5 PFLOP/s dense f16
-                    "issued_f16_mfma_tflops": round(N_PER_GPU * 15360 * 2 * S / (ev_mean * 1e-3) / 1e12, 1),
-                    "f16_mfma_peak_tflops": F16_MFMA_TFLOPS,
-                    "fp32_mfma_peak_tflops": F32_MFMA_TFLOPS,
-                    "frac_of_fp32_mfma_peak": round(achieved / F32_MFMA_TFLOPS, 4),
-                    "hbm_compulsory_frac": round(N_PER_GPU * bytes_per_sample_chain(D, 1) / (ev_mean * 1e-3) / 1e9
-                                                 / HBM_PEAK_GBS, 4)}
-    else:
-        roofline = None
-    k = 2 * S
+                            "splitting), not the matrix pipe or HBM")
+        # what the matrix pipe itself sees: 24 f16 MFMAs per 16 samples and layer
+        # (6 x 16x16x32 + 18 x 16x16x16) = 15,360 flop/sample/layer, against 2.5 PFLOP/s dense f16
+        roofline["issued_f16_mfma_tflops"] = round(N_PER_GPU * 15360 * 2 * S / (ev_mean * 1e-3) / 1e12, 1)
+        roofline["f16_mfma_peak_tflops"] = F16_MFMA_TFLOPS
     evl_mean = float(np.mean(ev_l))
-    chain_bytes = N_PER_GPU * bytes_per_sample_chain(D, k)
-    chain_gbs = chain_bytes / (evl_mean * 1e-3) / 1e9
     layer_chain = {
-        "value": round(N_PER_GPU / (evl_mean * 1e-3) / 1e6, 2), "unit": "M samples/s", "launches": k,
+        "value": round(N_PER_GPU / (evl_mean * 1e-3) / 1e6, 2), "unit": "M samples/s", "launches": 2 * S,
         "ms_per_step": round(evl_mean, 4),
-        "roofline": {"bound": "hbm", "kernel": "coupling_mfma_kernel<32,2,inverse>",
-                     "achieved": round(chain_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(chain_gbs / HBM_PEAK_GBS, 4),
-                     "traffic": read_traffic("coupling_mfma_kernel"),
-                     "algorithmic_bytes_per_sample_all_launches": bytes_per_sample_chain(D, k)},
+        "target_60pct_of_hbm_roof": round(0.6 * HBM_PEAK_GBS * 1e9 / bytes_per_sample_chain(D, 2 * S) / 1e6, 1),
+        "roofline": chain_roofline(D, evl_mean, N_PER_GPU, "coupling_mfma_kernel<32,2,inverse>"),
     }
     if roofline is None:
         roofline = layer_chain["roofline"]
@@ -376,32 +400,59 @@ def main():
                    "fusion": "whole-flow kernel (k=1), split-f16 MFMA" if fused else "one kernel per coupling layer (k=8)",
                    "arithmetic": "fp32 I/O, fp32 accumulate and VALU; matrix operands split hi+lo into f16",
                    "sharding": "samples, no collective in the timed region"},
+        "rccl_ranks": rccl_ranks,
+        "collective_backend": None if world == 1 else ("gloo, all ranks on cuda:0 (REHEARSAL, not a measurement)" if rehearse
+                                                       else "nccl (RCCL)"),
         "roofline": roofline,
         "layer_chain": layer_chain,
+        "strong_scaling": strong,
         "train_step": None if train_ms is None else {
             "ms": round(train_ms, 3), "samples_per_gpu": 1 << 19,
             "value": round((1 << 19) * world / (train_ms * 1e-3) / 1e6, 1), "unit": "M samples/s",
             "what": "loss = -mean(log_prob): whole-flow forward keeping z0, one-kernel reversible backward (split-f16 MFMA); "
-                    + ("RCCL all-reduce of the flat gradient; " if world > 1 else "") + "Adam step"},
+                    + ("RCCL all-reduce of the flat gradient (81,856 B, one bucket); " if world > 1 else "") + "Adam step"},
     }
 
     if world == 1 and not args.no_extras:
-        out["widened"] = widened_rows(tnf)
+        from tools import bench_rows
 
+        cfg = {}
+        # BASELINE configs[1]: D = 32, same depth
+        nf32 = build_model(32)
+        z32 = torch.randn(1, N_PER_GPU, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        _, e32, _ = run(nf32, z32, L_.FUSE_FLOW, 20, 3)
+        _, e32l, _ = run(nf32, z32, L_.FUSE_LAYER, 10, 2)
+        m32, m32l = float(np.mean(e32)), float(np.mean(e32l))
+        cfg["configs[1]"] = {
+            "what": "NormFlow(32,False,'coupling',4,2,15).log_prob, z (1, 2^20, 32)",
+            "value": round(N_PER_GPU / (m32 * 1e-3) / 1e6, 1), "unit": "M samples/s", "ms_per_step": round(m32, 4),
+            "roofline": fused_roofline(32, m32, N_PER_GPU, "flow_fused_f16_kernel<16,2,inverse,2,8,4>"),
+            "layer_chain": {"value": round(N_PER_GPU / (m32l * 1e-3) / 1e6, 1), "ms_per_step": round(m32l, 4),
+                            "roofline": chain_roofline(32, m32l, N_PER_GPU, "coupling_mfma_kernel<16,2,inverse>")}}
+        del nf32, z32
+        cfg["configs[2]"] = bench_rows.config2_row(tnf, dev)
+        out["configs"] = cfg
+        out["widened"] = bench_rows.widened_rows(tnf)
+
+    parity_ok = True
     if not args.no_cpu_baseline and world == 1:
-        threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-        base, orc, params, stats = cpu_baseline(nf, threads)
+        threads = args.cpu_threads or (os.cpu_count() or 1)
+        base, orc, params, stats = cpu_baseline(nf, threads, D, S, L, U)
         out["cpu_baseline"] = base
         sl = slice(1 << 19, (1 << 19) + (1 << 16))
         with torch.no_grad():
             want = orc.flow_log_prob(z[:, sl].cpu(), params, D, S, L, U, stats)
         rel = ((lp[:, sl].cpu() - want).abs() / want.abs().clamp_min(1e-3)).max().item()
         rel_l = ((lp_l[:, sl].cpu() - want).abs() / want.abs().clamp_min(1e-3)).max().item()
+        parity_ok = rel <= PARITY_TOL and rel_l <= PARITY_TOL
         out["parity"] = {"max_rel_err_vs_oracle": float("%.3g" % rel), "layer_chain_max_rel_err": float("%.3g" % rel_l),
-                         "samples": 1 << 16, "tolerance": 1e-5}
+                         "samples": 1 << 16, "tolerance": PARITY_TOL, "ok": parity_ok}
     print(json.dumps(out))
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    if not parity_ok:
+        sys.exit("bench.py: GPU log_prob differs from the oracle by more than %g -- the number above is INVALID" % PARITY_TOL)
 
 
 if __name__ == "__main__":

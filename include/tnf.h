@@ -359,6 +359,33 @@ int tnf_flow_forward_batch_f32(const float* omega, const float* params, float* z
                                int32_t num_stages, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                                float eps, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same chain in steps, for a caller that shards the samples over ranks ("one all-reduce of
+ * [sum z, sum z^2] per BatchNorm layer ... to reproduce the reference's full-batch statistics", bijectors.py:401-410).
+ * All steps share one workspace of tnf_flow_forward_batch_workspace_bytes() that must stay untouched in between:
+ *   begin                 builds the layers' operand images;
+ *   layer c (0..2S-1)     coupling layer c of this rank's rows (z_in = omega for c = 0, else z_out in place), then the
+ *                         LOCAL moments of its output: moments = [sum (D) | sum of squares (D) | row count], 2D+1
+ *                         doubles on the device, overwritten;
+ *   -- the caller sums `moments` over the ranks (RCCL all-reduce on the same stream); single rank: nothing --
+ *   fold c                statistics of the (global) batch -> rows c of bn_mean_out / bn_alpha_out (2S, D), and the
+ *                         BatchNorm (+ Affine) fold that the next layer's load stage applies;
+ *   end                   the last fold as an elementwise pass over z_out; sum_log_det += the constant log-dets.
+ * tnf_flow_forward_batch_f32 is this sequence with the local moments. */
+int tnf_flow_forward_batch_begin_f32(const float* params, int64_t M_p, int32_t D, int32_t num_stages, int32_t num_layers,
+                                     int32_t num_units, int64_t params_row_stride, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
+int tnf_flow_forward_batch_layer_f32(int32_t layer, const float* z_in, const float* params, float* z_out,
+                                     float* sum_log_det, double* moments, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                                     int32_t num_stages, int32_t num_layers, int32_t num_units,
+                                     int64_t params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
+int tnf_flow_forward_batch_fold_f32(int32_t layer, const float* params, const double* moments, float* bn_mean_out,
+                                    float* bn_alpha_out, int64_t M_p, int32_t D, int32_t num_stages, int32_t num_layers,
+                                    int32_t num_units, int64_t params_row_stride, float eps, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
+int tnf_flow_forward_batch_end_f32(float* z_out, float* sum_log_det, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                                   int32_t num_stages, int32_t num_layers, void* workspace, int64_t workspace_bytes,
+                                   void* stream);
+
 /* The same call under autograd (objectives on samples z = nf(N) and their log-density, e.g. the reference's
  * train_efn loop, with fresh batch statistics).  Forward: as above, out of place -- states (2*num_stages, M,N,D)
  * keeps every coupling layer's output before the fold behind it, folds (2*num_stages, M_p, 2, D) that fold's

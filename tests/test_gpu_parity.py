@@ -189,6 +189,68 @@ def test_golden_cde(tnf):
             torch.testing.assert_close(lp2.cpu(), T(g[k + "log_prob"], "cpu"), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["one_call_chain", "per_bijector"])
+def test_golden_cde_forward(tnf, fused):
+    """BASELINE configs[2], forward leg: `cde(x, N)` of the reference (conditional_density_estimator.py:93-99 ->
+    density_estimator.py:364-388, per-context parameter rows, fresh batch statistics) -- samples, float64
+    log-densities and the statistics each BatchNorm layer caches, against the reference's own outputs."""
+    g = load_golden("cde")
+    for ci, row in enumerate(g["meta"].tolist()):
+        D, S, L, U, D_x, nh, M, N = row[:8]
+        k = "d%02d_" % ci
+        nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+        nf.fused_batch_forward = fused
+        params = T(g[k + "params"])
+        with torch.no_grad():
+            z, lq = nf._forward_from(g[k + "omega"], params, freeze_bn=False)
+        assert z.dtype == torch.float32 and lq.dtype == torch.float64 and z.shape == (M, N, D)
+        torch.testing.assert_close(z.cpu(), T(g[k + "z_fwd"], "cpu"), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(lq.cpu(), T(g[k + "logq_fwd"], "cpu"), rtol=LOGP_RTOL, atol=2e-4)
+        for b, m, a in zip(nf._bn_layers(), g[k + "bn_mean"], g[k + "bn_alpha"]):
+            torch.testing.assert_close(b.get_last_mean().cpu(), T(m, "cpu"), rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(b.get_last_alpha().cpu(), T(a, "cpu"), rtol=1e-4, atol=1e-5)
+        sd = {n[len(k) + 3:]: T(g[n]) for n in g if n.startswith(k + "sd_")}
+        if sd:  # the whole module: param_net -> flow, host draw reproduced through np.random.seed-free injection
+            hidden = row[8:8 + nh]
+            cde = tnf.ConditionalDensityEstimator(nf, D_x, hidden)
+            cde.load_state_dict(sd)
+            with torch.no_grad():
+                p2 = cde._params_for(T(g[k + "x"]))
+                z2, lq2 = nf._forward_from(g[k + "omega"], p2, freeze_bn=False)
+            torch.testing.assert_close(z2.cpu(), T(g[k + "z_fwd"], "cpu"), rtol=2e-4, atol=2e-4)
+            torch.testing.assert_close(lq2.cpu(), T(g[k + "logq_fwd"], "cpu"), rtol=2e-5, atol=5e-4)
+
+
+@pytest.mark.parametrize("fusion", ["layer", "flow", "bijectors"])
+def test_golden_cde_frozen_forward(tnf, oracle, fusion, flow_variant):
+    """`cde(x, N, freeze_bn=True)` with the reference's cached statistics: the golden inputs through the per-layer
+    chain, the whole-flow kernel and the per-bijector loop, against the oracle's frozen forward on the same draw
+    (the oracle equals the reference bit for bit on these inputs, oracle/gen_golden.py)."""
+    g = load_golden("cde")
+    L_ = tnf._lib
+    for ci, row in enumerate(g["meta"].tolist()):
+        D, S, L, U, D_x, nh, M, N = row[:8]
+        k = "d%02d_" % ci
+        if fusion in ("layer", "flow") and not tnf.ops.has_fast_path(D, L, U):
+            continue
+        if fusion == "flow" and not L_.lib.tnf_flow_fused_supported(D, S, L, U):
+            continue
+        nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+        _install_stats(nf, g[k + "bn_mean"], g[k + "bn_alpha"])
+        nf.fusion = {"layer": L_.FUSE_LAYER, "flow": L_.FUSE_FLOW, "bijectors": L_.FUSE_AUTO}[fusion]
+        if fusion == "bijectors":
+            nf._fused_ok = lambda z, p: False
+        params = torch.from_numpy(g[k + "params"])
+        stats = [(torch.from_numpy(m), torch.from_numpy(a)) for m, a in zip(g[k + "bn_mean"], g[k + "bn_alpha"])]
+        z_want, lq_want, _ = oracle.flow_forward(g[k + "omega"], params, D, S, L, U, stats)
+        with torch.no_grad():
+            z, lq = nf._forward_from(g[k + "omega"], params.cuda(), freeze_bn=True)
+            lp = nf.log_prob(z, params.cuda())
+        torch.testing.assert_close(z.cpu(), z_want, rtol=2e-5, atol=1e-5)
+        torch.testing.assert_close(lq.cpu(), lq_want, rtol=LOGP_RTOL, atol=2e-5)
+        torch.testing.assert_close(lp.cpu().double(), lq_want, rtol=1e-4, atol=1e-3)  # forward <-> log_prob
+
+
 # --------------------------------------------------------------------------
 # 2. oracle on fresh inputs
 # --------------------------------------------------------------------------
@@ -243,6 +305,91 @@ def test_oracle_many_contexts(tnf, oracle, flow_variant):
         with torch.no_grad():
             got1 = nf.log_prob(z.cuda(), params[:1].cuda())
         torch.testing.assert_close(got1.cpu(), want1, rtol=LOGP_RTOL, atol=1e-5)
+
+
+def test_oracle_forward_many_contexts(tnf, oracle, flow_variant):
+    """BASELINE configs[2] shape family, forward leg at D = 64: per-context parameter rows (M_p = M > 1) through the
+    per-layer chain and the whole-flow kernel, frozen statistics, against the oracle's forward on the same draw; plus
+    fresh batch statistics (the reference's default `cde(x, N)`) through the one-call chain."""
+    D, S, L, U = 64, 4, 2, 15
+    for M, N in [(16, 512), (3, 40), (5, 17), (2, 33)]:
+        nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=100 + M, M=M)
+        omega = np.random.RandomState(M).normal(0, 1, (M, N, D))
+        z_want, lq_want, _ = oracle.flow_forward(omega, params, D, S, L, U, stats)
+        fusions = [tnf._lib.FUSE_LAYER, tnf._lib.FUSE_FLOW] if N >= 32 else [tnf._lib.FUSE_AUTO]
+        for fusion in fusions:
+            nf.fusion = fusion
+            with torch.no_grad():
+                z, lq = nf._forward_from(omega, params.cuda(), freeze_bn=True)
+            torch.testing.assert_close(z.cpu(), z_want, rtol=2e-5, atol=1e-5)
+            torch.testing.assert_close(lq.cpu(), lq_want, rtol=LOGP_RTOL, atol=2e-5)
+        nf.fusion = tnf._lib.FUSE_AUTO
+        zb_want, lqb_want, stb = oracle.flow_forward(omega, params, D, S, L, U, None)
+        with torch.no_grad():
+            zb, lqb = nf._forward_from(omega, params.cuda(), freeze_bn=False)
+        torch.testing.assert_close(zb.cpu(), zb_want, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(lqb.cpu(), lqb_want, rtol=LOGP_RTOL, atol=5e-4)
+        for b, (m, a) in zip(nf._bn_layers(), stb):
+            torch.testing.assert_close(b.get_last_mean().cpu(), m, rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(b.get_last_alpha().cpu(), a, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N", [(16, 1 << 16), (2048, 512)])
+def test_config2_full_size_properties(tnf, oracle, M, N):
+    """BASELINE configs[2] at its full size (SURVEY 8d cfg 3: ConditionalDensityEstimator over NormFlow(64, coupling,
+    4 stages), D_x = 32, hidden [64, 64], M*N = 2^20): `cde(x, N, freeze_bn=True)` then `cde.log_prob(z, x)`.
+    Size-independent properties where the oracle is too slow: forward <-> log_prob consistency, inverse(forward) round
+    trip, whole-flow kernel == per-layer chain == per-bijector loop, plus the oracle on a few contexts."""
+    D, S, L, U, D_x = 64, 4, 2, 15, 32
+    torch.manual_seed(5)
+    np.random.seed(5)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    cde = tnf.ConditionalDensityEstimator(nf, D_x, [64, 64])
+    rng = np.random.RandomState(M)
+    mean = rng.normal(0.0, 0.3, (2 * S, D)).astype(np.float32)
+    alpha = np.exp(rng.normal(0.0, 0.2, (2 * S, D))).astype(np.float32)
+    _install_stats(nf, mean, alpha)
+    stats = [(torch.from_numpy(m), torch.from_numpy(a)) for m, a in zip(mean, alpha)]
+    x = torch.randn(M, D_x, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    omega = torch.randn(M, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    L_ = tnf._lib
+    with torch.no_grad():
+        params = cde._params_for(x)
+        assert params.shape == (M, nf.D_params)
+        out = {}
+        for name, fusion in (("flow", L_.FUSE_FLOW), ("layer", L_.FUSE_LAYER)):
+            nf.fusion = fusion
+            z, lq = nf._forward_from(omega, params, freeze_bn=True)
+            lp = cde.log_prob(z, x)  # the public call: param_net again, then the flow kernels
+            z0, sld = nf.inverse_and_log_det(z, params)
+            out[name] = (z, lq, lp, z0, sld)
+        nf.fusion = L_.FUSE_AUTO
+    z, lq, lp, z0, sld = out["flow"]
+    assert z.shape == (M, N, D) and lq.dtype == torch.float64 and bool(torch.isfinite(lq).all())
+    # forward <-> log_prob (the reference's own check, tests/test_conditional_density_estimators.py:55-69)
+    torch.testing.assert_close(lp.double(), lq, rtol=1e-4, atol=2e-3)
+    # inverse(forward(omega)) == omega
+    torch.testing.assert_close(z0, omega, rtol=1e-4, atol=2e-4)
+    # whole-flow kernel == per-layer chain
+    torch.testing.assert_close(out["layer"][0], z, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out["layer"][1], lq, rtol=LOGP_RTOL, atol=1e-4)
+    torch.testing.assert_close(out["layer"][2], lp, rtol=LOGP_RTOL, atol=1e-4)
+    # ... == the per-bijector loop and == the oracle, on a few contexts
+    sel = torch.tensor([0, M // 2, M - 1], device="cuda")
+    nsub = min(N, 4096)
+    om_s, p_s = omega[sel][:, :nsub].contiguous(), params[sel].contiguous()
+    nf2 = tnf.NormFlow(D, True, "coupling", S, L, U)
+    _install_stats(nf2, mean, alpha)
+    nf2._fused_ok = lambda z_, p_: False
+    with torch.no_grad():
+        zb, lqb = nf2._forward_from(om_s, p_s, freeze_bn=True)
+    torch.testing.assert_close(zb, z[sel][:, :nsub], rtol=2e-5, atol=1e-5)
+    torch.testing.assert_close(lqb, lq[sel][:, :nsub], rtol=LOGP_RTOL, atol=1e-4)
+    z_want, lq_want, _ = oracle.flow_forward(om_s.double().cpu().numpy(), p_s.cpu(), D, S, L, U, stats)
+    torch.testing.assert_close(z[sel][:, :nsub].cpu(), z_want, rtol=2e-5, atol=1e-5)
+    torch.testing.assert_close(lq[sel][:, :nsub].cpu(), lq_want, rtol=LOGP_RTOL, atol=1e-4)
+    lp_want = oracle.flow_log_prob(z[sel][:, :nsub].cpu(), p_s.cpu(), D, S, L, U, stats)
+    torch.testing.assert_close(lp[sel][:, :nsub].cpu(), lp_want, rtol=LOGP_RTOL, atol=1e-5)
 
 
 def test_config0_plumbing(tnf, oracle):
@@ -476,3 +623,52 @@ def test_batch_stats_forward_full_size_round_trip(tnf):
     z2, lq2 = nf._forward_from(omega, p, freeze_bn=False)
     torch.testing.assert_close(z2.detach(), z, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(lq2.detach(), lq, rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("D,S,L,M,N,cut", [(64, 4, 2, 1, 5000, 1777), (32, 2, 3, 1, 700, 699), (64, 2, 2, 3, 333, 100)])
+def test_batch_stats_forward_sharded_steps(tnf, D, S, L, M, N, cut):
+    """SURVEY 8(e) bullet 3: a sample-sharded `nf(N, freeze_bn=False)` reproduces the single-device statistics when the
+    per-layer moments [sum | sum of squares | count] are summed over the shards between a layer and its fold.  Two
+    shards of one batch are driven in lockstep through the stepwise C ABI on one GPU (the all-reduce stands between
+    `layer` and `fold`; here it is a plain sum of the two moment vectors) and compared with the one-call chain over
+    the whole batch: samples, log-det sums and the cached statistics."""
+    U = 15
+    rng = np.random.RandomState(D + N)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    params = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float().cuda()
+    omega = torch.tensor(rng.normal(0, 1, (M, N, D))).float().cuda()
+    ops = tnf.ops
+    with torch.no_grad():
+        z_ref, sld_ref, mean_ref, alpha_ref = ops.flow_forward_batch_raw(omega, params, D, S, L, U, 1e-5)
+        shards = [ops.FlowForwardBatchSteps(omega[:, :cut].contiguous(), params, D, S, L, U, 1e-5),
+                  ops.FlowForwardBatchSteps(omega[:, cut:].contiguous(), params, D, S, L, U, 1e-5)]
+        for sh in shards:
+            sh.begin()
+        for c in range(2 * S):
+            moms = [sh.layer(c) for sh in shards]
+            total = moms[0] + moms[1]
+            assert float(total[2 * D].item()) == M * N
+            for mo in moms:
+                mo.copy_(total)
+            for sh in shards:
+                sh.fold(c)
+        outs = [sh.end() for sh in shards]
+    z = torch.cat([o[0] for o in outs], dim=1)
+    sld = torch.cat([o[1] for o in outs], dim=1)
+    torch.testing.assert_close(z, z_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(sld, sld_ref, rtol=1e-5, atol=1e-4)
+    for o in outs:  # every shard ends up with the statistics of the whole batch
+        torch.testing.assert_close(o[2], mean_ref, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(o[3], alpha_ref, rtol=1e-5, atol=1e-6)
+    # the reducer hook of NormFlow: with an identity "all-reduce" (one rank) the stepwise path equals the one call
+    calls = []
+    nf.batch_stats_reduce = lambda mo: calls.append(mo.shape) or mo
+    with torch.no_grad():
+        z1, lq1 = nf._forward_from(omega, params, freeze_bn=False)
+    assert len(calls) == 2 * S and calls[0] == (2 * D + 1,)
+    torch.testing.assert_close(z1, z_ref, rtol=0, atol=0)
+    nf.batch_stats_reduce = None
+    # ... and a path that cannot honour the reducer says so instead of using local statistics
+    nf.batch_stats_reduce = lambda mo: mo
+    with pytest.raises(NotImplementedError):
+        nf._forward_from(omega, params.clone().requires_grad_(), freeze_bn=False)

@@ -80,6 +80,12 @@ SIGNATURES = {
     "tnf_flow_forward_batch_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "tnf_flow_forward_batch_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32,
                                                   _i32, _i64, ctypes.c_float, _vp, _i64, _vp]),
+    "tnf_flow_forward_batch_begin_f32": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _vp, _i64, _vp]),
+    "tnf_flow_forward_batch_layer_f32": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32,
+                                                        _i32, _i64, _vp, _i64, _vp]),
+    "tnf_flow_forward_batch_fold_f32": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64,
+                                                       ctypes.c_float, _vp, _i64, _vp]),
+    "tnf_flow_forward_batch_end_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "tnf_flow_forward_train_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32, _i32]),
     "tnf_flow_forward_train_fwd_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                                       _i32, _i32, _i64, ctypes.c_float, _vp, _i64, _vp]),

@@ -929,6 +929,70 @@ int tnf_flow_forward_batch_f32(const float* omega, const float* params, float* z
                                      pstride, eps, workspace, as_stream(stream));
 }
 
+// The same chain in steps (see coupling_mfma.hip): begin, then per coupling layer c = 0 .. 2S-1 `layer` (kernel + LOCAL
+// moments of its output) and `fold` (statistics from the moments the caller may have summed over ranks), then end.
+static int fb_step_checks(const char* fn, int64_t M_p, int D, int S, int L, int U, int64_t pstride, const void* ws,
+                          int64_t ws_bytes) {
+    if (M_p < 1 || S < 1) return fail(TNF_EINVAL, "%s: M_p=%lld S=%d", fn, (long long)M_p, S);
+    if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "%s: no kernel for D=%d L=%d U=%d", fn, D, L, U);
+    if (pstride < flow_layout(D, S, L, U).total)
+        return fail(TNF_EINVAL, "%s: params row has %lld elements, flow needs %lld", fn, (long long)pstride,
+                    (long long)flow_layout(D, S, L, U).total);
+    if (!ws || ws_bytes < flow_forward_batch_workspace(M_p, D, S, L))
+        return fail(TNF_EWORKSPACE, "%s: workspace %lld < %lld", fn, (long long)ws_bytes,
+                    (long long)flow_forward_batch_workspace(M_p, D, S, L));
+    return TNF_OK;
+}
+
+int tnf_flow_forward_batch_begin_f32(const float* params, int64_t M_p, int32_t D, int32_t S, int32_t L, int32_t U,
+                                     int64_t pstride, void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* fn = "tnf_flow_forward_batch_begin_f32";
+    int rc = fb_step_checks(fn, M_p, D, S, L, U, pstride, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!params) return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    return flow_forward_batch_begin(params, M_p, D, S, L, U, pstride, workspace, as_stream(stream));
+}
+
+int tnf_flow_forward_batch_layer_f32(int32_t layer, const float* z_in, const float* params, float* z_out,
+                                     float* sum_log_det, double* moments, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                                     int32_t S, int32_t L, int32_t U, int64_t pstride, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    const char* fn = "tnf_flow_forward_batch_layer_f32";
+    int rc = fb_step_checks(fn, M_p, D, S, L, U, pstride, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0) return fail(TNF_EINVAL, "%s: M=%lld M_p=%lld N=%lld", fn, (long long)M, (long long)M_p, (long long)N);
+    if (layer < 0 || layer >= 2 * S) return fail(TNF_EINVAL, "%s: layer %d of %d", fn, layer, 2 * S);
+    if (!params || !moments || (N > 0 && (!z_in || !z_out || !sum_log_det))) return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    if (!aligned16(z_in) || !aligned16(z_out) || (reinterpret_cast<uintptr_t>(moments) & 7))
+        return fail(TNF_EINVAL, "%s: z_in / z_out must be 16-byte and moments 8-byte aligned", fn);
+    if (layer == 0 && z_in == z_out) return fail(TNF_EINVAL, "%s: z_out must not alias the base draw", fn);
+    return flow_forward_batch_layer(layer, z_in, params, z_out, sum_log_det, moments, M, M_p, N, D, S, L, U, pstride,
+                                    workspace, as_stream(stream));
+}
+
+int tnf_flow_forward_batch_fold_f32(int32_t layer, const float* params, const double* moments, float* bn_mean_out,
+                                    float* bn_alpha_out, int64_t M_p, int32_t D, int32_t S, int32_t L, int32_t U,
+                                    int64_t pstride, float eps, void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* fn = "tnf_flow_forward_batch_fold_f32";
+    int rc = fb_step_checks(fn, M_p, D, S, L, U, pstride, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (layer < 0 || layer >= 2 * S) return fail(TNF_EINVAL, "%s: layer %d of %d", fn, layer, 2 * S);
+    if (!params || !moments || !bn_mean_out || !bn_alpha_out) return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    return flow_forward_batch_fold(layer, params, moments, bn_mean_out, bn_alpha_out, M_p, D, S, L, U, pstride, eps, workspace,
+                                   as_stream(stream));
+}
+
+int tnf_flow_forward_batch_end_f32(float* z_out, float* sum_log_det, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                                   int32_t S, int32_t L, void* workspace, int64_t workspace_bytes, void* stream) {
+    const char* fn = "tnf_flow_forward_batch_end_f32";
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0 || D < 2 || S < 1 || L < 1)
+        return fail(TNF_EINVAL, "%s: M=%lld M_p=%lld N=%lld D=%d", fn, (long long)M, (long long)M_p, (long long)N, D);
+    if (!workspace || workspace_bytes < flow_forward_batch_workspace(M_p, D, S, L))
+        return fail(TNF_EWORKSPACE, "%s: workspace too small", fn);
+    if (N > 0 && (!z_out || !sum_log_det)) return fail(TNF_EINVAL, "%s: NULL pointer", fn);
+    return flow_forward_batch_end(z_out, sum_log_det, M, M_p, N, D, workspace, as_stream(stream));
+}
+
 // ... and the same stack under autograd (sampling-based objectives): forward keeps every coupling layer's output
 int64_t tnf_flow_forward_train_workspace_bytes(int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L) {
     if (M < 1 || (M_p != 1 && M_p != M) || N < 0 || D < 2 || S < 1 || L < 1)

@@ -486,38 +486,58 @@ flow_fold_apply_kernel(const float* z, float* z_out, float* __restrict__ sld, co
 
 static int64_t fb_head_bytes(int64_t Mp, int D) { return (((Mp * 2 * D + Mp + D + 1) * 4 + 15) / 16) * 16; }
 int64_t flow_forward_batch_workspace(int64_t Mp, int D, int S, int L) {
-    // fold (Mp, 2, D) | ldc (Mp) | rstd (D) | ld_bn (1) | sums (2 D doubles) | operand images (Mp, 2S, image)
-    return fb_head_bytes(Mp, D) + 2 * (int64_t)D * 8 + Mp * 2 * S * mfma_image_floats(D, L) * 4;
+    // fold (Mp, 2, D) | ldc (Mp) | rstd (D) | ld_bn (1) | moments (2 D + 2 doubles) | operand images (Mp, 2S, image)
+    return fb_head_bytes(Mp, D) + (2 * (int64_t)D + 2) * 8 + Mp * 2 * S * mfma_image_floats(D, L) * 4;
 }
 
-int launch_flow_forward_batch(const float* omega, const float* params, float* z_out, float* sum_log_det,
-                              float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t Mp, int64_t N, int D, int S,
-                              int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st) {
+// The chain in steps, so that a sample-sharded caller can put a collective between a layer's local moments and the
+// statistics derived from them (one all-reduce of [sum, sum of squares, count] per BatchNorm layer):
+//   begin                    operand images of every layer (workspace)
+//   layer c                  coupling layer c with the fold behind layer c-1 in its load stage; then the LOCAL moments
+//                            of its output: moments = [sum (D) | sum of squares (D) | row count] doubles, overwritten
+//   (caller: sum `moments` over the ranks that share the batch)
+//   fold c                   statistics from the (global) moments -> bn_mean_out / bn_alpha_out row c, fold constants
+//                            for the next layer's load stage, constant log-det
+//   end                      the last fold as an elementwise pass; sum_log_det += constant log-dets
+// tnf_flow_forward_batch_f32 is exactly begin, (layer, fold) x 2S, end with the local moments.
+struct FbWs {
+    float *fold, *ldc, *rstd, *ld_bn, *images;
+    double* moments;
+};
+static FbWs fb_ws(void* ws, int64_t Mp, int D) {
+    FbWs w;
+    w.fold = reinterpret_cast<float*>(ws);
+    w.ldc = w.fold + Mp * 2 * D;
+    w.rstd = w.ldc + Mp;
+    w.ld_bn = w.rstd + D;
+    w.moments = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + fb_head_bytes(Mp, D));
+    w.images = reinterpret_cast<float*>(w.moments + 2 * D + 2);
+    return w;
+}
+
+int flow_forward_batch_begin(const float* params, int64_t Mp, int D, int S, int L, int U, int64_t pstride, void* ws,
+                             hipStream_t st) {
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "flow_forward_batch: D=%d L=%d U=%d", D, L, U);
-    if (N <= 0) return TNF_OK;
-    float* fold = reinterpret_cast<float*>(ws);
-    float* ldc = fold + Mp * 2 * D;
-    float* rstd = ldc + Mp;
-    float* ld_bn = rstd + D;
-    double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + fb_head_bytes(Mp, D));
-    float* images = reinterpret_cast<float*>(sums + 2 * D);
+    return launch_flow_images(params, fb_ws(ws, Mp, D).images, Mp, D, S, L, U, pstride, st);
+}
+
+int flow_forward_batch_layer(int c, const float* z_in, const float* params, float* z_out, float* sum_log_det,
+                             double* moments, int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U, int64_t pstride,
+                             void* ws, hipStream_t st) {
+    const FbWs w = fb_ws(ws, Mp, D);
     const FlowLayout fl = flow_layout(D, S, L, U);
     const int nl = 2 * S;
     const int64_t img_floats = mfma_image_floats(D, L);
-    {
-        int rc = launch_flow_images(params, images, Mp, D, S, L, U, pstride, st);
-        if (rc) return rc;
-    }
-    const int64_t rows = M * N;
-    for (int c = 0; c < nl; ++c) {
+    if (!moments) moments = w.moments;
+    if (N > 0) {
         MfmaLayerArgs a = {};
-        a.z = c == 0 ? omega : z_out;
+        a.z = z_in;
         a.z_out = z_out;
         a.params = params + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
         a.pstride = pstride;
-        a.image = images + (int64_t)c * img_floats;
+        a.image = w.images + (int64_t)c * img_floats;
         a.image_stride = (int64_t)nl * img_floats;
-        a.pre = c == 0 ? nullptr : fold;
+        a.pre = c == 0 ? nullptr : w.fold;
         a.fold_stride = 2 * (int64_t)D;
         a.ld_in = c == 0 ? nullptr : sum_log_det;
         a.ld_out = sum_log_det;
@@ -526,18 +546,50 @@ int launch_flow_forward_batch(const float* omega, const float* params, float* z_
         a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 0;
         int rc = launch_coupling_mfma(a, st);
         if (rc) return rc;
-        rc = launch_bn_stats(z_out, sums, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D, rstd, ld_bn, rows, D,
-                             eps, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(flow_batch_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
-                           (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, bn_mean_out + (int64_t)c * D, rstd, ld_bn,
-                           fold, ldc, D, c & 1, c == 0);
     }
+    return launch_bn_moments(z_out, moments, M * N, D, st);  // an empty shard contributes zeros
+}
+
+int flow_forward_batch_fold(int c, const float* params, const double* moments, float* bn_mean_out, float* bn_alpha_out,
+                            int64_t Mp, int D, int S, int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st) {
+    const FbWs w = fb_ws(ws, Mp, D);
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    if (!moments) moments = w.moments;
+    int rc = launch_bn_finalize(moments, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D, w.rstd, w.ld_bn, D, eps,
+                                st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flow_batch_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
+                       (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, bn_mean_out + (int64_t)c * D, w.rstd, w.ld_bn,
+                       w.fold, w.ldc, D, c & 1, c == 0);
+    return check_launch("flow_forward_batch_fold");
+}
+
+int flow_forward_batch_end(float* z_out, float* sum_log_det, int64_t M, int64_t Mp, int64_t N, int D, void* ws,
+                           hipStream_t st) {
+    if (N <= 0) return TNF_OK;
+    const FbWs w = fb_ws(ws, Mp, D);
     int64_t nb = (N * D / 4 + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(flow_fold_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, z_out, z_out, sum_log_det, fold, ldc, Mp,
+    hipLaunchKernelGGL(flow_fold_apply_kernel, grid_xm(nb, M), dim3(256), 0, st, z_out, z_out, sum_log_det, w.fold, w.ldc, Mp,
                        N, D);
-    return check_launch("flow_forward_batch");
+    return check_launch("flow_forward_batch_end");
+}
+
+int launch_flow_forward_batch(const float* omega, const float* params, float* z_out, float* sum_log_det,
+                              float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t Mp, int64_t N, int D, int S,
+                              int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st) {
+    if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "flow_forward_batch: D=%d L=%d U=%d", D, L, U);
+    if (N <= 0) return TNF_OK;
+    int rc = flow_forward_batch_begin(params, Mp, D, S, L, U, pstride, ws, st);
+    if (rc) return rc;
+    for (int c = 0; c < 2 * S; ++c) {
+        rc = flow_forward_batch_layer(c, c == 0 ? omega : z_out, params, z_out, sum_log_det, nullptr, M, Mp, N, D, S, L, U,
+                                      pstride, ws, st);
+        if (rc) return rc;
+        rc = flow_forward_batch_fold(c, params, nullptr, bn_mean_out, bn_alpha_out, Mp, D, S, L, U, pstride, eps, ws, st);
+        if (rc) return rc;
+    }
+    return flow_forward_batch_end(z_out, sum_log_det, M, Mp, N, D, ws, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -698,11 +750,9 @@ int launch_flow_forward_train_fwd(const float* omega, const float* params, float
                                   int D, int S, int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st) {
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "flow_forward_train: D=%d L=%d U=%d", D, L, U);
     if (N <= 0) return TNF_OK;
-    float* ldc = reinterpret_cast<float*>(ws) + Mp * 2 * D;
-    float* rstd = ldc + Mp;
-    float* ld_bn = rstd + D;
-    double* sums = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + fb_head_bytes(Mp, D));
-    float* images = reinterpret_cast<float*>(sums + 2 * D);
+    const FbWs w = fb_ws(ws, Mp, D);
+    float *ldc = w.ldc, *rstd = w.rstd, *ld_bn = w.ld_bn, *images = w.images;
+    double* sums = w.moments;
     const FlowLayout fl = flow_layout(D, S, L, U);
     const int nl = 2 * S;
     const int64_t img_floats = mfma_image_floats(D, L), plane = M * N * D;
@@ -725,8 +775,9 @@ int launch_flow_forward_train_fwd(const float* omega, const float* params, float
         a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 0;
         rc = launch_coupling_mfma(a, st);
         if (rc) return rc;
-        rc = launch_bn_stats(states + (int64_t)c * plane, sums, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D,
-                             rstd, ld_bn, M * N, D, eps, st);
+        rc = launch_bn_moments(states + (int64_t)c * plane, sums, M * N, D, st);
+        if (rc) return rc;
+        rc = launch_bn_finalize(sums, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D, rstd, ld_bn, D, eps, st);
         if (rc) return rc;
         hipLaunchKernelGGL(flow_batch_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
                            (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, bn_mean_out + (int64_t)c * D, rstd, ld_bn,

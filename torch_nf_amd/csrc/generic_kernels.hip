@@ -347,12 +347,15 @@ bn_stats_vec_kernel(const float* __restrict__ z, double* __restrict__ sums, int6
 __global__ void __launch_bounds__(256)
 bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean_out,
                    float* __restrict__ alpha_out, float* __restrict__ rstd, float* __restrict__ log_det,
-                   int64_t rows, int D, float eps) {
+                   int64_t rows_arg, int D, float eps) {
     __shared__ float red[256];
     float acc = 0.f;
+    // rows_arg < 0: the row count rides behind the sums (moments = [sum (D) | sum of squares (D) | count]) -- the
+    // count of the GLOBAL batch when the moments were summed over the ranks of a sample-sharded forward
+    const double rows = rows_arg < 0 ? sums[2 * D] : (double)rows_arg;
     for (int d = threadIdx.x; d < D; d += 256) {
-        const double mu = sums[d] / (double)rows;
-        double var_b = sums[D + d] / (double)rows - mu * mu;
+        const double mu = sums[d] / rows;
+        double var_b = sums[D + d] / rows - mu * mu;
         if (var_b < 0.0) var_b = 0.0;
         const double a = sqrt(var_b + (double)eps);
         mean_out[d] = (float)mu;
@@ -396,19 +399,29 @@ static void launch_bn_sums(const float* z, double* sums, int64_t rows, int D, in
     }
 }
 
-// statistics only (the normalisation is folded into the next kernel by the caller): sums is scratch of 2 D doubles
-int launch_bn_stats(const float* z, double* sums, float* mean_out, float* alpha_out, float* rstd, float* log_det,
-                    int64_t rows, int D, float eps, hipStream_t st) {
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)D, st) != hipSuccess)
-        return fail(TNF_ELAUNCH, "bn_stats: memset failed");
-    int64_t blocks = (rows + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    const int64_t rpb = (rows + blocks - 1) / blocks;
-    launch_bn_sums(z, sums, rows, D, blocks, rpb, st);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, sums, mean_out, alpha_out, rstd, log_det, rows, D,
-                       eps);
-    return TNF_OK;
+// local moments of z (rows, D) for a batch-statistics BatchNorm whose normalisation is folded into the next kernel by
+// the caller: moments = [sum (D) | sum of squares (D) | row count] doubles, overwritten
+__global__ void bn_count_kernel(double* __restrict__ moments, int D, double rows) { moments[2 * D] = rows; }
+
+int launch_bn_moments(const float* z, double* moments, int64_t rows, int D, hipStream_t st) {
+    if (hipMemsetAsync(moments, 0, sizeof(double) * 2 * (size_t)D, st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "bn_moments: memset failed");
+    hipLaunchKernelGGL(bn_count_kernel, dim3(1), dim3(1), 0, st, moments, D, (double)rows);
+    if (rows > 0) {
+        int64_t blocks = (rows + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        const int64_t rpb = (rows + blocks - 1) / blocks;
+        launch_bn_sums(z, moments, rows, D, blocks, rpb, st);
+    }
+    return check_launch("bn_moments");
+}
+
+// mean / alpha / 1/alpha / log-det from moments (the count is read from moments[2 D])
+int launch_bn_finalize(const double* moments, float* mean_out, float* alpha_out, float* rstd, float* log_det, int D,
+                       float eps, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, moments, mean_out, alpha_out, rstd, log_det,
+                       (int64_t)-1, D, eps);
+    return check_launch("bn_finalize");
 }
 
 int launch_bn_batch_forward(const float* z, float* z_out, float* mean_out, float* alpha_out,

@@ -131,9 +131,19 @@ int launch_flow_fused_f16(const float* z, const float* images, const float* fold
                           const float* bn_alpha = nullptr,  // fold == NULL: folded inside the kernel from these
                           const float* interval_consts = nullptr);  // fused ToInterval support layer (7, D)
 
-int launch_bn_stats(const float* z, double* sums, float* mean_out, float* alpha_out, float* rstd, float* log_det,
-                    int64_t rows, int D, float eps, hipStream_t st);
+int launch_bn_moments(const float* z, double* moments, int64_t rows, int D, hipStream_t st);
+int launch_bn_finalize(const double* moments, float* mean_out, float* alpha_out, float* rstd, float* log_det, int D,
+                       float eps, hipStream_t st);
 int64_t flow_forward_batch_workspace(int64_t Mp, int D, int S, int L);
+int flow_forward_batch_begin(const float* params, int64_t Mp, int D, int S, int L, int U, int64_t pstride, void* ws,
+                             hipStream_t st);
+int flow_forward_batch_layer(int c, const float* z_in, const float* params, float* z_out, float* sum_log_det,
+                             double* moments, int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U, int64_t pstride,
+                             void* ws, hipStream_t st);
+int flow_forward_batch_fold(int c, const float* params, const double* moments, float* bn_mean_out, float* bn_alpha_out,
+                            int64_t Mp, int D, int S, int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st);
+int flow_forward_batch_end(float* z_out, float* sum_log_det, int64_t M, int64_t Mp, int64_t N, int D, void* ws,
+                           hipStream_t st);
 int launch_flow_forward_batch(const float* omega, const float* params, float* z_out, float* sum_log_det,
                               float* bn_mean_out, float* bn_alpha_out, int64_t M, int64_t Mp, int64_t N, int D, int S,
                               int L, int U, int64_t pstride, float eps, void* ws, hipStream_t st);

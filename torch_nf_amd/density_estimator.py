@@ -115,6 +115,9 @@ class NormFlow(DensityEstimator):
                 else torch.device("cpu")
         self.device = torch.device(device)
         self.fusion = _lib.FUSE_AUTO
+        # sample-sharded sampling with fresh statistics (one process per GPU): a callable that sums a BatchNorm layer's
+        # [sum | sum of squares | count] moments over the ranks sharing the batch (distributed.moment_reducer(group))
+        self.batch_stats_reduce = None
 
         self.bijectors = []
         if self.arch_type == "coupling":
@@ -263,6 +266,14 @@ class NormFlow(DensityEstimator):
 
         sup = self._fused_support()
         support_done = False
+        if (not freeze_bn and self.batch_stats_reduce is not None
+                and not (self._fused_ok(z, p_dev) and self._batch_chain_ok(z, p_dev))):
+            # sharded statistics exist only in the stepwise no-autograd chain: anything else would silently
+            # normalise with this rank's local moments
+            raise NotImplementedError(
+                "NormFlow.batch_stats_reduce is set (sample-sharded batch statistics), but this call does not take the "
+                "one-call batch-statistics chain (needs arch_type='coupling', float32, no autograd, D in {32, 64}, "
+                "num_units <= 16, num_layers <= 3, one parameter row per z row).")
         if freeze_bn and self._ar_fused_ok(z, p_dev) and sup is not False:
             z, sld = ops.ar_flow_forward_raw(z, p_dev, *self._ar_args(), interval_consts=sup)
             log_q = log_q - sld
@@ -276,12 +287,13 @@ class NormFlow(DensityEstimator):
             log_q = log_q - sld
             support_done = fuse_sup
         elif (not freeze_bn and self._fused_ok(z, p_dev) and self._batch_chain_ok(z, p_dev)
-              and z.size(0) * z.size(1) > 1):
+              and (z.size(0) * z.size(1) > 1 or self.batch_stats_reduce is not None)):
             # fresh batch statistics, no autograd: one call for the whole stack; every BatchNorm layer ends up with
             # the statistics its own forward(use_last=False) would have cached
             bns = self._bn_layers()
             z, sld, means, alphas = ops.flow_forward_batch_raw(z, p_dev, self.D, self.num_stages, self.num_layers,
-                                                               self.num_units, bns[0].eps)
+                                                               self.num_units, bns[0].eps,
+                                                               reduce_moments=self.batch_stats_reduce)
             for i, b in enumerate(bns):
                 b.set_last_stats(means[i], alphas[i])
             log_q = log_q - sld

@@ -56,15 +56,33 @@ def allreduce_gradients(params, group=None, average=False):
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
+    # RCCL reduces and averages in one collective; gloo (the CPU tests) has no AVG
+    avg_op = average and dist.get_backend(group) == "nccl"
+    op = dist.ReduceOp.AVG if avg_op else dist.ReduceOp.SUM
+    if len(grads) == 1 and grads[0].is_contiguous():
+        # the flow's own parameter row (NormFlow.params, 81,856 B at D=64): reduced IN PLACE -- one latency-bound
+        # collective and no staging kernels around it
+        dist.all_reduce(grads[0], op=op, group=group)
+        if average and not avg_op:
+            grads[0] /= dist.get_world_size(group)
+        return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
+    dist.all_reduce(flat, op=op, group=group)
+    if average and not avg_op:
         flat /= dist.get_world_size(group)
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
-        off += n
+    torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+
+def moment_reducer(group=None):
+    """The exchange step of a sample-sharded batch-statistics forward: a callable that sums, in place and across the
+    ranks of `group`, the float64 [sum (D) | sum of squares (D) | row count] moments a BatchNorm layer's input has on
+    this rank.  Install it as `NormFlow.batch_stats_reduce`: `nf(N, freeze_bn=False)` on every rank's shard then
+    normalises with (and caches) the statistics of the global batch (bijectors.py:401-415 over all ranks' rows) --
+    the 2*num_stages small all-reduces SURVEY 8(e) prescribes, enqueued between a layer kernel and its fold."""
+    def reduce_(moments):
+        dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
+        return moments
+    return reduce_
 
 
 def allreduce_moments(count, total, total_sq, group=None):

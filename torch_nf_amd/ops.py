@@ -373,12 +373,21 @@ def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.F
 # flow level, with autograd: log_prob through one fused kernel per layer, backward through one
 # MFMA backward kernel per layer (tnf_flow_log_prob_fwd_f32 / _bwd_f32)
 # ---------------------------------------------------------------------------
-def flow_forward_batch_raw(omega, params, D, S, L, U, eps):
+def flow_forward_batch_raw(omega, params, D, S, L, U, eps, reduce_moments=None):
     """tnf_flow_forward_batch_f32: NormFlow.forward with batch-statistics BatchNorm and no autograd in one call
-    -> (z, sum_log_det, bn_mean (2S, D), bn_alpha (2S, D)), all on the compute device."""
+    -> (z, sum_log_det, bn_mean (2S, D), bn_alpha (2S, D)), all on the compute device.
+
+    reduce_moments: optional callable applied IN PLACE to the (2D + 1,) float64 device tensor [sum | sum of squares |
+    row count] of every BatchNorm layer's input before its statistics are formed -- for a sample-sharded forward this
+    is the all-reduce over the ranks that share the batch (torch_nf_amd.distributed.moment_reducer), after which every
+    rank normalises with the statistics of the GLOBAL batch exactly as the single-device call would
+    (bijectors.py:401-415).  The chain then runs in steps (tnf_flow_forward_batch_begin / _layer / _fold / _end_f32)
+    with the collective on the same stream between a layer and its fold."""
     dev = _lib.require_device()
     oc = _stage(omega.detach(), dev)
     pc, pstride = _rows(params.detach(), dev)
+    if reduce_moments is not None:
+        return run_batch_steps(FlowForwardBatchSteps(oc, pc, D, S, L, U, eps), reduce_moments)
     M, N = oc.shape[0], oc.shape[1]
     Mp = pc.shape[0]
     z = torch.empty_like(oc)
@@ -391,6 +400,69 @@ def flow_forward_batch_raw(omega, params, D, S, L, U, eps):
                                          alpha.data_ptr(), M, Mp, N, D, S, L, U, pstride, float(eps), ws.data_ptr(),
                                          nbytes, _lib.stream_ptr()))
     return z, sld, mean, alpha
+
+
+class FlowForwardBatchSteps:
+    """One rank's share of a batch-statistics forward, step by step (tnf_flow_forward_batch_begin / _layer / _fold /
+    _end_f32): `layer(c)` returns this rank's moments of layer c's output, `fold(c)` consumes the moments AS THEY ARE
+    THEN (summed over the ranks by the caller) -- see run_batch_steps."""
+
+    def __init__(self, omega, params, D, S, L, U, eps):
+        dev = _lib.require_device()
+        self.omega = _stage(omega.detach(), dev)
+        self.params, self.pstride = _rows(params.detach(), dev)
+        self.cfg = (D, S, L, U)
+        self.eps = float(eps)
+        self.n_layers = 2 * S
+        M, N = self.omega.shape[0], self.omega.shape[1]
+        self.M, self.N, self.Mp = M, N, self.params.shape[0]
+        self.z = torch.empty_like(self.omega)
+        self.sld = torch.empty((M, N), dtype=torch.float32, device=dev)
+        self.mean = torch.empty((2 * S, D), dtype=torch.float32, device=dev)
+        self.alpha = torch.empty((2 * S, D), dtype=torch.float32, device=dev)
+        self.nbytes = check(lib.tnf_flow_forward_batch_workspace_bytes(self.Mp, D, S, L))
+        # a workspace of its own: it must survive the collectives between the steps
+        self.ws = torch.empty(self.nbytes, dtype=torch.uint8, device=dev)
+        self.moments = torch.empty(2 * D + 1, dtype=torch.float64, device=dev)
+
+    def begin(self):
+        D, S, L, U = self.cfg
+        check(lib.tnf_flow_forward_batch_begin_f32(self.params.data_ptr(), self.Mp, D, S, L, U, self.pstride,
+                                                   self.ws.data_ptr(), self.nbytes, _lib.stream_ptr()))
+
+    def layer(self, c):
+        D, S, L, U = self.cfg
+        src = self.omega if c == 0 else self.z
+        check(lib.tnf_flow_forward_batch_layer_f32(c, src.data_ptr(), self.params.data_ptr(), self.z.data_ptr(),
+                                                   self.sld.data_ptr(), self.moments.data_ptr(), self.M, self.Mp, self.N,
+                                                   D, S, L, U, self.pstride, self.ws.data_ptr(), self.nbytes,
+                                                   _lib.stream_ptr()))
+        return self.moments
+
+    def fold(self, c):
+        D, S, L, U = self.cfg
+        check(lib.tnf_flow_forward_batch_fold_f32(c, self.params.data_ptr(), self.moments.data_ptr(), self.mean.data_ptr(),
+                                                  self.alpha.data_ptr(), self.Mp, D, S, L, U, self.pstride, self.eps,
+                                                  self.ws.data_ptr(), self.nbytes, _lib.stream_ptr()))
+
+    def end(self):
+        D, S, L, U = self.cfg
+        check(lib.tnf_flow_forward_batch_end_f32(self.z.data_ptr(), self.sld.data_ptr(), self.M, self.Mp, self.N, D, S, L,
+                                                 self.ws.data_ptr(), self.nbytes, _lib.stream_ptr()))
+        return self.z, self.sld, self.mean, self.alpha
+
+
+def run_batch_steps(steps, reduce_moments=None):
+    """The sequence of a (sample-sharded) batch-statistics forward over any object with the FlowForwardBatchSteps
+    protocol: per coupling layer, the rank-local kernel + moments, then the exchange (`reduce_moments`: in-place sum
+    over the ranks that share the batch; None on a single rank), then the fold built from the global moments."""
+    steps.begin()
+    for c in range(steps.n_layers):
+        moments = steps.layer(c)
+        if reduce_moments is not None:
+            reduce_moments(moments)
+        steps.fold(c)
+    return steps.end()
 
 
 class _FlowForwardTrainFn(torch.autograd.Function):
