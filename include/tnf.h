@@ -328,6 +328,17 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
                           int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                           int32_t fusion, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* tnf_flow_log_prob_f32 with a diagnostic output: *exact_reruns (one uint32 on the device, zeroed by the caller) is
+ * incremented once per 32-sample group that the whole-flow kernel had to re-run with exact fp32 first-layer
+ * contractions because a conditioner input left the range of its split-f16 operand (|x| 2^-kappa >= 65520; see
+ * torch_nf_amd/csrc/f16_tile2.h).  The results are the same with or without the counter; the reference
+ * (bijectors.py:237-241, plain fp32 matmul) has no such range, and neither has the result of this call. */
+int tnf_flow_log_prob_diag_f32(const float* z, const float* params, const float* bn_mean, const float* bn_alpha,
+                               const float* interval_consts, float* log_prob, float* z0, float* sum_log_det, int64_t M_z,
+                               int64_t M_p, int64_t N, int32_t D, int32_t num_stages, int32_t num_layers,
+                               int32_t num_units, int64_t params_row_stride, int32_t fusion, void* workspace,
+                               int64_t workspace_bytes, void* stream, uint32_t* exact_reruns);
+
 /* Training pair for loss = f(NormFlow.log_prob(z)) (the reference differentiates
  * density_estimator.py:390-416 with torch autograd).  The forward runs one fused kernel per
  * coupling layer and keeps each kernel's INPUT in `states` (2*S - 1, M, N, D) -- states[c] is the

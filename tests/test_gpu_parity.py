@@ -41,10 +41,12 @@ def _force_generic(tnf, on):
     tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FORCE_GENERIC, int(on)))
 
 
-DEFAULT_FLOW_VARIANT = 10  # split-f16 whole-flow kernel; 0 = the fp32-MFMA whole-flow kernel
+# 10 = the default whole-flow kernels (inverse: flow_fused2.hip, forward: flow_fused_f16.hip); 15 = the first split-f16
+# formulation in both directions (flow_fused_f16.hip); 0 = the fp32-MFMA whole-flow kernel (flow_fused.hip)
+DEFAULT_FLOW_VARIANT = 10
 
 
-@pytest.fixture(params=[10, 0], ids=["wholeflow_f16split", "wholeflow_f32mfma"])
+@pytest.fixture(params=[10, 15, 0], ids=["wholeflow_default", "wholeflow_f16split_v1", "wholeflow_f32mfma"])
 def flow_variant(request, tnf):
     """Run a test once per whole-flow kernel implementation (both sit behind TNF_FUSE_FLOW)."""
     tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FLOW_VARIANT, request.param))
@@ -674,3 +676,72 @@ def test_batch_stats_forward_sharded_steps(tnf, D, S, L, M, N, cut):
     nf.batch_stats_reduce = lambda mo: mo
     with pytest.raises(NotImplementedError):
         nf._forward_from(omega, params.clone().requires_grad_(), freeze_bn=False)
+
+
+def _rel_err(got, want):
+    return ((got.double() - want.double()).abs() / want.double().abs().clamp_min(1e-3)).max().item()
+
+
+@pytest.mark.parametrize("D", [64, 32])
+def test_operand_range(tnf, oracle, D):
+    """The reference is plain fp32 (bijectors.py:172,198,237-241) and has no operand range; the default path computes
+    its contractions on split-f16 operands, which do.  These inputs leave the comfortable range on purpose: samples
+    scaled by 1e5, BatchNorm means of 1e5, first-layer weights of 1e-6 (with large inputs, so that their products are
+    O(1)) and of 1e3, everything scaled down by 1e-5.  Truth = the oracle's arithmetic in float64; the bar is rtol
+    1e-5 on log_prob, or four times the float32 oracle's own deviation from float64 where fp32 itself cannot do better.
+    The power-of-two operand normalisation keeps the small / large weight cases on the fast path; inputs whose scaled
+    magnitude passes 65520 are detected and those groups re-run exactly (counted by the diagnostic entry point)."""
+    S, L, U, N = 4, 2, 15, 3000
+    ops, L_ = tnf.ops, tnf._lib
+    h = D // 2
+
+    def scale_layer0(params, fac):
+        """multiply the first-layer weights (W_t, W_s of the h -> U layer) of every coupling layer by fac"""
+        p = params.clone()
+        lay = oracle.flow_layout(D, S, L, U)
+        off = 0
+        for kind, n, up in lay:
+            if kind == "coupling":
+                p[:, off:off + 2 * h * U] *= fac
+            off += n
+        return p
+
+    cases = {}
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=77)
+    z = torch.randn(1, N, D, generator=torch.Generator().manual_seed(3))
+    cases["plain"] = (z, params, stats, False)
+    cases["z_1e5"] = (z * 1e5, params, stats, True)
+    # None: whether any group leaves the fast path depends on the draw -- only the result is checked
+    cases["z_3e4_partly"] = (torch.where(torch.rand(1, N, 1, generator=torch.Generator().manual_seed(4)) < 0.01, z * 3e4, z),
+                             params, stats, None)
+    cases["bn_mean_1e5"] = (z, params, [(m + 1e5, a) for m, a in stats], None)
+    cases["w0_1e-6_z_1e5"] = (z * 1e5, scale_layer0(params, 1e-5), stats, False)
+    cases["w0_1e3"] = (z, scale_layer0(params, 1e4), stats, None)
+    cases["all_params_1e-5"] = (z, params * 1e-5, stats, False)
+    for name, (zz, pp, st, expect_reruns) in cases.items():
+        want64 = oracle.flow_log_prob(zz.double(), pp.double(), D, S, L, U, [(m.double(), a.double()) for m, a in st])
+        want32 = oracle.flow_log_prob(zz, pp, D, S, L, U, st)
+        assert torch.isfinite(want64).all(), name
+        bar = max(LOGP_RTOL, 4.0 * _rel_err(want32, want64))
+        _install_stats(nf, [m.numpy() for m, _ in st], [a.numpy() for _, a in st])
+        mean, alpha = nf._bn_stats(torch.device("cuda"))
+        with torch.no_grad():
+            lp, z0, sld, reruns = ops.flow_log_prob_raw(zz.cuda(), pp.cuda(), mean, alpha, D, S, L, U, L_.FUSE_FLOW,
+                                                        want_z0=True, want_sld=True, count_reruns=True)
+            lp_l, _, _ = ops.flow_log_prob_raw(zz.cuda(), pp.cuda(), mean, alpha, D, S, L, U, L_.FUSE_LAYER)
+        err = _rel_err(lp.cpu(), want64)
+        assert err <= bar, "%s: whole-flow kernel rel err %.3g > %.3g (float32 oracle: %.3g)" % (
+            name, err, bar, _rel_err(want32, want64))
+        assert _rel_err(lp_l.cpu(), want64) <= bar, name + " (per-layer chain)"
+        n_re = int(reruns.item())
+        if expect_reruns is True:
+            assert n_re > 0, name + ": out-of-range inputs must take the exact path"
+        elif expect_reruns is False:
+            assert n_re == 0, name + ": %d groups left the fast path" % n_re
+        st64 = [(m.double(), a.double()) for m, a in st]
+        z0_want, _ = oracle.flow_inverse(zz.double(), pp.double(), D, S, L, U, st64)
+        z0_f32, _ = oracle.flow_inverse(zz, pp, D, S, L, U, st)
+        scale = z0_want.abs().amax(dim=2, keepdim=True).clamp_min(1.0)  # per sample: its largest coordinate
+        zerr = ((z0.cpu().double() - z0_want).abs() / scale).max().item()
+        zbar = max(2e-5, 4.0 * ((z0_f32.double() - z0_want).abs() / scale).max().item())
+        assert zerr <= zbar, "%s: z0 err %.3g > %.3g" % (name, zerr, zbar)

@@ -11,7 +11,7 @@ import os
 import torch  # imported first so the HIP runtime torch ships is the one the library binds to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtnf_hip.so")
+LIB_PATH = os.environ.get("TNF_LIB_PATH") or os.path.join(_HERE, "lib", "libtnf_hip.so")  # override: kernel A/B builds
 
 F32, F64 = 0, 1
 LD_STORE, LD_ADD, LD_SUB = 0, 1, -1
@@ -72,6 +72,8 @@ SIGNATURES = {
     "tnf_flow_fused_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "tnf_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
                                              _i32, _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
+    "tnf_flow_log_prob_diag_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
+                                                  _i32, _i32, _i32, _i64, _i32, _vp, _i64, _vp, _vp]),
     "tnf_flow_train_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "tnf_flow_log_prob_fwd_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32,
                                                  _i32, _i64, _vp, _i64, _vp]),

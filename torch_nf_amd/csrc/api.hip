@@ -6,7 +6,7 @@
 
 namespace tnf {
 
-int g_force_generic = 0;
+thread_local int g_force_generic = 0;
 
 char* err_buf() {
     static thread_local char buf[512] = {0};
@@ -618,12 +618,12 @@ static int flow_common_checks(const char* fn, int64_t M_z, int64_t M_p, int64_t 
     return TNF_OK;
 }
 
-int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_mean,
+static int flow_log_prob_impl(const float* z, const float* params, const float* bn_mean,
                           const float* bn_alpha, const float* interval_consts, float* log_prob, float* z0,
                           float* sum_log_det,
                           int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L,
                           int32_t U, int64_t pstride, int32_t fusion, void* workspace,
-                          int64_t workspace_bytes, void* stream) {
+                          int64_t workspace_bytes, void* stream, uint32_t* exact_reruns) {
     int use_fused = 0;
     int rc = flow_common_checks("tnf_flow_log_prob_f32", M_z, M_p, N, D, S, L, U, pstride, fusion,
                                 workspace, workspace_bytes, &use_fused);
@@ -646,6 +646,9 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
     const bool f16 = use_fused && g_flow_variant >= 10;  // builds its own (split-f16) images
     if (interval_consts && !f16)
         return fail(TNF_EUNSUPPORTED, "tnf_flow_log_prob_f32: a fused support layer needs the whole-flow kernel");
+    if (f16 && g_flow_variant == 10 && flow_fused2_supported(D, S, L, U))  // default: second formulation (f16_tile2.h)
+        return launch_flow_fused2(z, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha,
+                                  interval_consts, exact_reruns, st);
     if (f16)  // ONE launch: the flow kernel builds its split-f16 operands and folds BN / Affine in its prologue
         return launch_flow_fused_f16(z, nullptr, nullptr, nullptr, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U,
                                      1, g_flow_variant, st, params, pstride, bn_mean, bn_alpha, interval_consts);
@@ -687,6 +690,28 @@ int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_m
         if (rc) return rc;
     }
     return TNF_OK;
+}
+
+int tnf_flow_log_prob_f32(const float* z, const float* params, const float* bn_mean,
+                          const float* bn_alpha, const float* interval_consts, float* log_prob, float* z0,
+                          float* sum_log_det,
+                          int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L,
+                          int32_t U, int64_t pstride, int32_t fusion, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    return flow_log_prob_impl(z, params, bn_mean, bn_alpha, interval_consts, log_prob, z0, sum_log_det, M_z, M_p, N, D, S, L,
+                              U, pstride, fusion, workspace, workspace_bytes, stream, nullptr);
+}
+
+/* Same call with a diagnostic: *exact_reruns (device word, caller zeroes it) += the number of 32-sample groups the
+ * whole-flow kernel re-ran with exact fp32 first-layer contractions because a conditioner input left the f16
+ * operand range (f16_tile2.h, point 3).  Results do not depend on it. */
+int tnf_flow_log_prob_diag_f32(const float* z, const float* params, const float* bn_mean,
+                               const float* bn_alpha, const float* interval_consts, float* log_prob, float* z0,
+                               float* sum_log_det, int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L,
+                               int32_t U, int64_t pstride, int32_t fusion, void* workspace, int64_t workspace_bytes,
+                               void* stream, uint32_t* exact_reruns) {
+    return flow_log_prob_impl(z, params, bn_mean, bn_alpha, interval_consts, log_prob, z0, sum_log_det, M_z, M_p, N, D, S, L,
+                              U, pstride, fusion, workspace, workspace_bytes, stream, exact_reruns);
 }
 
 // ---- training pair: log_prob with saved per-layer inputs, and its backward ----
@@ -874,6 +899,9 @@ int tnf_flow_log_prob_fwd_rev_f32(const float* z, const float* params, const flo
     if (!z || !params || !bn_mean || !bn_alpha || !log_prob || !z0)
         return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_rev_f32: NULL pointer");
     if (!aligned16(z) || !aligned16(z0)) return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_rev_f32: z / z0 must be 16-byte aligned");
+    if (g_flow_variant == 10 && flow_fused2_supported(D, S, L, U))
+        return launch_flow_fused2(z, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha, nullptr,
+                                  nullptr, as_stream(stream));
     return launch_flow_fused_f16(z, nullptr, nullptr, nullptr, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, 1,
                                  g_flow_variant >= 10 ? g_flow_variant : 10, as_stream(stream), params, pstride, bn_mean,
                                  bn_alpha, nullptr);

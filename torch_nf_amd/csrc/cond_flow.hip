@@ -433,7 +433,7 @@ static int launch_cond_variant(const CondArgs& a, hipStream_t st) {
     return check_launch("cond_flow");
 }
 
-int g_cond_variant = 0;  // testing hook: 0 = by M, 1 = (BT 1, 4 waves), 2 = (BT 1, 8 waves), 3 = (BT 2, 8 waves)
+thread_local int g_cond_variant = 0;  // testing hook: 0 = by M, 1 = (BT 1, 4 waves), 2 = (BT 1, 8 waves), 3 = (BT 2, 8 waves)
 
 template <int DT, int KS>
 static int launch_cond_dk(const CondArgs& a, hipStream_t st) {

@@ -20,11 +20,11 @@ __device__ __forceinline__ f4 cmfma32h(h8 a, h8 b, f4 c) {
 __device__ __forceinline__ void csplit2(float v0, float v1, unsigned& hi, unsigned& lo) {
     const auto h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
     const unsigned hb = __builtin_bit_cast(unsigned, h);
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(v0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(v1));
+    // in place ("+v"), never into a fresh register: the inline-asm rule of f16_tile.h
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(hb));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(hb));
     hi = hb;
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
 }
 __device__ __forceinline__ void csplit8(f4 v0, f4 v1, h8& hi, h8& lo) {
     unsigned a0, a1, a2, a3, b0, b1, b2, b3;

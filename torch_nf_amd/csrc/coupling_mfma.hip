@@ -362,8 +362,8 @@ bool mfma_supported(int D, int L, int U) {
 // Launch-geometry variants (g_layer_variant, TNF_OPT_LAYER_VARIANT):
 //   0: operands in registers, 2 tiles per wave iteration     1: operands in LDS, 2 tiles
 //   2: operands in LDS, 1 tile                               3: operands in registers, 1 tile
-int g_layer_variant = 0;
-int g_train_bwd_fp32 = 0;
+thread_local int g_layer_variant = 0;
+thread_local int g_train_bwd_fp32 = 0;
 
 template <int H, int L, bool INV, int NT, bool LDSOP>
 static void launch_k(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {

@@ -11,6 +11,13 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
+// Inline-asm rule of this code base (measured the hard way, flow_fused2.hip round 2): hipcc neither sees the registers
+// an asm VALU instruction READS as results of an in-flight MFMA, nor pads the WAR / WAW hazards of the registers it
+// WRITES against MFMAs still reading (SrcC, up to 7 wait states for an 8-pass MFMA) or writing them.  A fresh "=v"
+// output may land in exactly such a register -- results then change with the schedule and from run to run.  So an asm
+// VALU instruction here only ever (a) reads results of ordinary VALU instructions and (b) writes IN PLACE ("+v") over a
+// value an ordinary VALU instruction produced after the MFMAs in question: the compiler resolved every MFMA hazard of
+// that register when it scheduled the producer, and it copies the value first (v_mov, visible) if it is still live.
 // two floats -> packed (hi, hi) and (lo, lo) f16 pairs
 struct HiLo {
     unsigned hi, lo;
@@ -24,10 +31,10 @@ __device__ __forceinline__ HiLo split2v(float v0, float v1) {
     // select v_fma_mix_f32 for this pattern; it emits v_cvt_f32_f16 + v_sub_f32).  Exact: the
     // difference of v and its rtz-f16 truncation is representable in fp32.
     const unsigned hb = __builtin_bit_cast(unsigned, h);
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(v0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(v1));
-    const auto l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    // the remainder replaces the value IN PLACE ("+v"): see the inline-asm rule above
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(hb));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(hb));
+    const auto l = __builtin_amdgcn_cvt_pkrtz(v0, v1);
     return HiLo{hb, __builtin_bit_cast(unsigned, l)};
 }
 // (vector elements cannot bind to references, hence the macro)

@@ -290,15 +290,14 @@ struct FxAcc {
 };
 // max(m, |a|, |b|) in one instruction.  a and b must be results of ordinary VALU instructions: the compiler does
 // not see inside the asm, so it would not insert the wait states an MFMA result needs before a VALU reads it.
+// Written IN PLACE ("+v") like every asm VALU result here: the inline-asm rule of f16_tile.h.
 __device__ __forceinline__ float amax3(float m, float a, float b) {
-    float r;
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-    return r;
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+    return m;
 }
 __device__ __forceinline__ int fx_cvt(float scaled) {
-    int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(scaled));  // floor(x + 0.5), saturating
-    return r;
+    asm("v_cvt_rpi_i32_f32 %0, %0" : "+v"(scaled));  // floor(x + 0.5), saturating; the int replaces the float's bits
+    return __builtin_bit_cast(int, scaled);
 }
 // all four values of every lane are real (padded entries receive exact zeros)
 __device__ __forceinline__ void lds_add4(int* p, f4 v, FxAcc& fa) {

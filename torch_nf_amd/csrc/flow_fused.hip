@@ -205,7 +205,7 @@ flow_fused_kernel(FlowFusedArgs a) {
 // (tiles per wave iteration, waves per workgroup) variants; index = g_flow_variant
 // (TNF_OPT_FLOW_VARIANT, a tuning hook).  One workgroup per CU (LDS-limited), so the
 // waves-per-workgroup choice IS the occupancy choice: 8 -> 2 waves/SIMD ... 16 -> 4.
-int g_flow_variant = 10;  // default: the split-f16 whole-flow kernel (flow_fused_f16.hip); 0..5 select the fp32-MFMA kernel
+thread_local int g_flow_variant = 10;  // default: the split-f16 whole-flow kernel (flow_fused_f16.hip); 0..5 select the fp32-MFMA kernel
 
 template <int H, int L>
 static size_t flow_lds_bytes(int S) {

@@ -198,11 +198,10 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
             int* p = reinterpret_cast<int*>(gdst + g * 256);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float t = v[j] * a.fx;  // a plain VALU result: safe to read from inline asm (flow_bwd_f16.hip)
+                float t = v[j] * a.fx;  // a plain VALU result, converted in place: the inline-asm rule of f16_tile.h
                 amax = fmaxf(amax, fabsf(t));
-                int r;
-                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(t));
-                atomicAdd(p + j, r);
+                asm("v_cvt_rpi_i32_f32 %0, %0" : "+v"(t));
+                atomicAdd(p + j, __builtin_bit_cast(int, t));
             }
         } else {
 #pragma unroll

@@ -62,12 +62,13 @@ __host__ __device__ inline FlowLayout flow_layout(int D, int S, int L, int U) {
     return f;
 }
 
-// ---- runtime options (testing hooks) ---------------------------------------
-extern int g_force_generic;
-extern int g_flow_variant;   // flow_fused.hip
-extern int g_layer_variant;  // coupling_mfma.hip
-extern int g_train_bwd_fp32; // coupling_mfma.hip
-extern int g_cond_variant;   // cond_flow.hip
+// ---- runtime options (testing hooks; per calling thread, like the error string: tnf_set_option changes the
+// kernel selection of the thread that called it and of no other) ---------------------------------------------
+extern thread_local int g_force_generic;
+extern thread_local int g_flow_variant;   // flow_fused.hip
+extern thread_local int g_layer_variant;  // coupling_mfma.hip
+extern thread_local int g_train_bwd_fp32; // coupling_mfma.hip
+extern thread_local int g_cond_variant;   // cond_flow.hip
 
 // ---- kernels implemented in the .hip files ----------------------------------
 int launch_coupling_generic(int dtype, const void* z, const void* params, void* z_out,
@@ -121,6 +122,11 @@ int launch_flow_fused(const float* z, const float* images, const float* fold, co
                       float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
                       int64_t N, int D, int S, int L, int U, int inverse, hipStream_t st);
 bool flow_fused_supported(int D, int S, int L, int U);
+// whole-flow inverse kernel, second formulation (flow_fused2.hip / f16_tile2.h)
+bool flow_fused2_supported(int D, int S, int L, int U);
+int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
+                       int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
+                       const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st);
 // split-f16 variant of the whole-flow kernel (flow_fused_f16.hip); images in slots of mfma_image_floats(D, 3)
 int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,
                            int64_t pstride, hipStream_t st);

@@ -303,9 +303,11 @@ def _workspace(nbytes, dev):
 
 
 def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO,
-                      want_z0=False, want_sld=False, want_lp=True, interval_consts=None):
+                      want_z0=False, want_sld=False, want_lp=True, interval_consts=None, count_reruns=False):
     """tnf_flow_log_prob_f32.  Returns (log_prob | None, z0 | None, sum_log_det | None).
-    interval_consts: (7, D) device constants of a ToInterval support layer fused into the whole-flow kernel."""
+    interval_consts: (7, D) device constants of a ToInterval support layer fused into the whole-flow kernel.
+    count_reruns: also return a one-element int32 device tensor = the number of 32-sample groups the whole-flow kernel
+    re-ran with exact fp32 first-layer contractions (inputs outside the split-f16 operand range; tnf_flow_log_prob_diag_f32)."""
     _check3(z)
     dev = _lib.require_device()
     home = z.device
@@ -326,17 +328,22 @@ def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE
         return tuple(t.to(home) if t is not None else None for t in (lp, z0, sld))
     ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, L, U, fusion))
     ws = _workspace(ws_bytes, dev)
-    check(lib.tnf_flow_log_prob_f32(
-        zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
-        None if interval_consts is None else interval_consts.data_ptr(),
-        lp.data_ptr() if want_lp else None, z0.data_ptr() if want_z0 else None,
-        sld.data_ptr() if want_sld else None, Mz, Mp, N, D, S, L, U, pstride, fusion, ws.data_ptr(),
-        ws.numel(), _lib.stream_ptr()))
+    args = (zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+            None if interval_consts is None else interval_consts.data_ptr(),
+            lp.data_ptr() if want_lp else None, z0.data_ptr() if want_z0 else None,
+            sld.data_ptr() if want_sld else None, Mz, Mp, N, D, S, L, U, pstride, fusion, ws.data_ptr(),
+            ws.numel(), _lib.stream_ptr())
+    reruns = None
+    if count_reruns:
+        reruns = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.tnf_flow_log_prob_diag_f32(*args, reruns.data_ptr()))
+    else:
+        check(lib.tnf_flow_log_prob_f32(*args))
     if home != dev:
         lp = lp.to(home) if want_lp else None
         z0 = z0.to(home) if want_z0 else None
         sld = sld.to(home) if want_sld else None
-    return lp, z0, sld
+    return (lp, z0, sld, reruns) if count_reruns else (lp, z0, sld)
 
 
 def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO, interval_consts=None):
