@@ -171,7 +171,7 @@ def cpu_baseline(nf, threads, D, S, L, U):
     params = nf.params.detach().cpu()
     stats = [(b.get_last_mean().cpu(), b.get_last_alpha().cpu()) for b in nf._bn_layers()]
     rows = []
-    for thr, n, reps in ([(min(16, threads), 1 << 19, 2)] + ([(threads, 1 << 17, 1)] if threads > 16 else [])):
+    for thr, n, reps in ([(min(16, threads), 1 << 19, 2)] + ([(threads, 1 << 14, 1)] if threads > 16 else [])):
         z = torch.randn(1, n, D, generator=torch.Generator().manual_seed(1))
         best = _time_oracle(torch, orc, z, params, D, S, L, U, stats, thr, reps)
         rows.append({"value": round(n / best / 1e6, 4), "cores": thr, "samples": n, "reps": "1 warm-up + best of %d" % reps})

@@ -54,6 +54,15 @@ def flow_variant(request, tnf):
     tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FLOW_VARIANT, DEFAULT_FLOW_VARIANT))
 
 
+@pytest.fixture(params=[10, 12, 0], ids=["chain_f16split", "chain_f16split_2layers_per_launch", "chain_f32mfma"])
+def layer_variant(request, tnf):
+    """Run a test once per implementation of the per-layer chain (TNF_FUSE_LAYER): the whole-flow kernel's tile code
+    with one (10) or two (12) coupling layers per launch, and the fp32-MFMA layer kernel with half-row stores (0)."""
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_LAYER_VARIANT, request.param))
+    yield request.param
+    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_LAYER_VARIANT, 10))
+
+
 # --------------------------------------------------------------------------
 # 1. golden vectors
 # --------------------------------------------------------------------------
@@ -124,7 +133,7 @@ def _install_stats(nf, mean, alpha):
 
 
 @pytest.mark.parametrize("fusion", ["auto", "layer", "flow", "bijectors"])
-def test_golden_flow(tnf, fusion, flow_variant):
+def test_golden_flow(tnf, fusion, flow_variant, layer_variant):
     g = load_golden("flow")
     L_ = tnf._lib
     for ci in range(len(g["meta"])):
@@ -276,7 +285,7 @@ def _rand_flow(tnf, D, S, L, U, seed, sigma=0.1, M=1):
                                        (64, 2, 2, 20, 2049), (64, 2, 2, 64, 1000), (16, 3, 2, 15, 777),
                                        (8, 2, 3, 20, 333), (128, 1, 2, 32, 500), (24, 2, 5, 17, 450),
                                        (40, 2, 1, 50, 129), (64, 4, 4, 15, 64)])
-def test_oracle_log_prob(tnf, oracle, flow_variant, D, S, L, U, N):
+def test_oracle_log_prob(tnf, oracle, flow_variant, layer_variant, D, S, L, U, N):
     nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=N + D)
     z = torch.randn(1, N, D, generator=torch.Generator().manual_seed(1))
     want = oracle.flow_log_prob(z, params, D, S, L, U, stats)
@@ -290,7 +299,7 @@ def test_oracle_log_prob(tnf, oracle, flow_variant, D, S, L, U, N):
         torch.testing.assert_close(got.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
 
 
-def test_oracle_many_contexts(tnf, oracle, flow_variant):
+def test_oracle_many_contexts(tnf, oracle, flow_variant, layer_variant):
     """M_p = M_z > 1 (per-context weights, cfg 3 shape family) and M_p = 1 broadcast."""
     D, S, L, U = 64, 4, 2, 15
     for M, N in [(16, 512), (3, 40), (64, 1), (5, 17)]:
@@ -481,7 +490,7 @@ def test_full_size_layer_roundtrip(tnf):
     torch.testing.assert_close(ldi, ldf, rtol=1e-5, atol=1e-6)
 
 
-def test_edge_shapes(tnf, oracle, flow_variant):
+def test_edge_shapes(tnf, oracle, flow_variant, layer_variant):
     """Ragged / tiny inputs: N below one MFMA tile, N = 1, tails that are not a multiple of 16 or 32."""
     D, S, L, U = 64, 4, 2, 15
     nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=21)

@@ -644,7 +644,8 @@ static int flow_log_prob_impl(const float* z, const float* params, const float* 
     const bool narrow = mfma_supported(D, L, U);
     const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
     const bool f16 = use_fused && g_flow_variant >= 10;  // builds its own (split-f16) images
-    if (interval_consts && !f16)
+    const bool chain2 = !use_fused && narrow && g_layer_variant >= 10 && flow_range2_supported(D, L, U, 1);
+    if (interval_consts && !f16 && !chain2)
         return fail(TNF_EUNSUPPORTED, "tnf_flow_log_prob_f32: a fused support layer needs the whole-flow kernel");
     if (f16 && g_flow_variant == 10 && flow_fused2_supported(D, S, L, U))  // default: second formulation (f16_tile2.h)
         return launch_flow_fused2(z, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha,
@@ -652,7 +653,18 @@ static int flow_log_prob_impl(const float* z, const float* params, const float* 
     if (f16)  // ONE launch: the flow kernel builds its split-f16 operands and folds BN / Affine in its prologue
         return launch_flow_fused_f16(z, nullptr, nullptr, nullptr, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U,
                                      1, g_flow_variant, st, params, pstride, bn_mean, bn_alpha, interval_consts);
-    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride, 1, st);
+    if (!use_fused && narrow && g_layer_variant >= 10 && flow_range2_supported(D, L, U, 1)) {
+        // default per-layer chain: the whole-flow kernel's tile code, ONE coupling layer per launch (flow_fused2.hip)
+        float* zb = z0 ? z0 : reinterpret_cast<float*>(wsb + w.zbuf);
+        float* lb = sum_log_det ? sum_log_det : reinterpret_cast<float*>(wsb + w.ldbuf);
+        return launch_flow_chain2(z, zb, lb, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean,
+                                  bn_alpha, interval_consts, exact_reruns, g_layer_variant >= 11 ? g_layer_variant - 10 : 1, st);
+    }
+    // fp32-MFMA per-layer chain on the narrow shapes: in place from the second kernel on, each kernel storing only the
+    // half it transforms (the folds are composed accordingly, flow_fold_kernel chain = 1)
+    const int chain = (!use_fused && narrow) ? 1 : 0;
+    rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride, 1, st,
+                          chain);
     if (rc) return rc;
     if (!narrow) {
         rc = launch_wide_images(params, images, M_p, D, S, L, U, pstride, st);
@@ -686,6 +698,7 @@ static int flow_log_prob_impl(const float* z, const float* params, const float* 
         a.log_prob = last ? log_prob : nullptr;
         a.Mz = first ? M_z : M; a.Mp = M_p; a.N = N;
         a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 1;
+        a.skip_cond_store = (chain && !first && !(last && z0)) ? 1 : 0;
         rc = narrow ? launch_coupling_mfma(a, st) : launch_coupling_wide(a, st);
         if (rc) return rc;
     }

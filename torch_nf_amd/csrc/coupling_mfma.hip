@@ -19,10 +19,39 @@ namespace tnf {
 // ldc[m] = sum of all parameter-only log-dets: sum_s sum(a_s) - sum_c sum(log alpha_c)
 // (bijectors.py:293, 417).   fold layout: (Mp, 2S, 2, D) floats.
 // ---------------------------------------------------------------------------
+//
+// chain = 1 (the in-place inverse chain of tnf_flow_log_prob_f32, one kernel per layer, walked c = 2S-1 .. 0): from the
+// second kernel on a kernel stores only the half it transforms; the conditioner half stays in memory as it was BEFORE
+// this kernel's fold, and that fold is owed to it.  It is paid by the next kernel, which transforms exactly that half:
+// for c <= 2S-3 the constants of the transformed half of layer c are  fold_c o fold_{c+1}.  (520 -> 392 B per sample and
+// launch at D = 64.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void fold_consts(const float* __restrict__ p, const float* __restrict__ bn_mean,
+                                            const float* __restrict__ bn_alpha, const FlowLayout& fl, int D, int c, int d,
+                                            int inverse, float& A, float& B, float& ld) {
+    const float alpha = bn_alpha[c * D + d], mu = bn_mean[c * D + d];
+    ld = -logf(alpha);
+    float ea = 1.f, shift = 0.f;
+    if (c & 1) {
+        const float* ap = p + (c >> 1) * fl.stage + fl.p_up + fl.p_low;
+        const float a = ap[d];
+        ld += a;
+        ea = expf(a);
+        shift = ap[D + d];
+    }
+    if (inverse) {
+        A = alpha / ea;
+        B = mu - shift * A;
+    } else {
+        A = ea / alpha;
+        B = shift - mu * A;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_mean,
                  const float* __restrict__ bn_alpha, float* __restrict__ fold,
-                 float* __restrict__ ldc, int D, int S, int L, int U, int64_t pstride, int inverse) {
+                 float* __restrict__ ldc, int D, int S, int L, int U, int64_t pstride, int inverse, int chain) {
     __shared__ float red[256];
     const int m = blockIdx.x;
     const float* p = params + (int64_t)m * pstride;
@@ -30,24 +59,15 @@ flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_
     float acc = 0.f;
     for (int idx = threadIdx.x; idx < 2 * S * D; idx += 256) {
         const int c = idx / D, d = idx - c * D;
-        const int stage = c >> 1;
-        float A, B;
-        const float alpha = bn_alpha[c * D + d], mu = bn_mean[c * D + d];
-        acc -= logf(alpha);
-        float ea = 1.f, shift = 0.f;
-        if (c & 1) {
-            const float* ap = p + stage * fl.stage + fl.p_up + fl.p_low;
-            const float a = ap[d];
-            acc += a;
-            ea = expf(a);
-            shift = ap[D + d];
-        }
-        if (inverse) {
-            A = alpha / ea;
-            B = mu - shift * A;
-        } else {
-            A = ea / alpha;
-            B = shift - mu * A;
+        float A, B, ld;
+        fold_consts(p, bn_mean, bn_alpha, fl, D, c, d, inverse, A, B, ld);
+        acc += ld;
+        // layer c transforms the upper half when c is even (density_estimator.py:260-270: RealNVP(upper) first)
+        if (chain && c <= 2 * S - 3 && ((d >= D / 2) == ((c & 1) == 0))) {
+            float A1, B1, ld1;
+            fold_consts(p, bn_mean, bn_alpha, fl, D, c + 1, d, inverse, A1, B1, ld1);
+            B = __builtin_fmaf(A, B1, B);
+            A = A * A1;
         }
         float* f = fold + (((int64_t)m * 2 * S + c) * 2) * D;
         f[d] = A;
@@ -145,9 +165,9 @@ int launch_flow_images(const float* params, float* images, int64_t Mp, int D, in
 
 int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
                      float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
-                     int64_t pstride, int inverse, hipStream_t st) {
+                     int64_t pstride, int inverse, hipStream_t st, int chain) {
     hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
-                       bn_alpha, fold, ldc, D, S, L, U, pstride, inverse);
+                       bn_alpha, fold, ldc, D, S, L, U, pstride, inverse, chain);
     if (!images) return check_launch("flow_prep");  // wide shapes build their own images
     return launch_flow_images(params, images, Mp, D, S, L, U, pstride, st);
 }
@@ -345,7 +365,7 @@ coupling_mfma_kernel(MfmaLayerArgs a) {
                 float* zr = zo + row * D + 4 * q;
 #pragma unroll
                 for (int mm = 0; mm < HT; ++mm) {
-                    *reinterpret_cast<f4*>(zr + c_off + 16 * mm) = x[t][mm];
+                    if (!a.skip_cond_store) *reinterpret_cast<f4*>(zr + c_off + 16 * mm) = x[t][mm];
                     *reinterpret_cast<f4*>(zr + t_off + 16 * mm) = y[t][mm];
                 }
             }
@@ -359,10 +379,12 @@ bool mfma_supported(int D, int L, int U) {
     return U >= 1 && U <= 16;
 }
 
-// Launch-geometry variants (g_layer_variant, TNF_OPT_LAYER_VARIANT):
+// Per-layer chain variants (g_layer_variant, TNF_OPT_LAYER_VARIANT):
+//   10 (default): split-f16 tile code of the whole-flow kernel, one coupling layer per launch (flow_fused2.hip);
+//   10 + n: n layers per launch;   0..3: this file's fp32-MFMA kernel --
 //   0: operands in registers, 2 tiles per wave iteration     1: operands in LDS, 2 tiles
 //   2: operands in LDS, 1 tile                               3: operands in registers, 1 tile
-thread_local int g_layer_variant = 0;
+thread_local int g_layer_variant = 10;
 thread_local int g_train_bwd_fp32 = 0;
 
 template <int H, int L, bool INV, int NT, bool LDSOP>
@@ -385,7 +407,7 @@ static void launch_k(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {
 
 template <int H, int L, bool INV>
 static void launch_v(const MfmaLayerArgs& a, int64_t M, hipStream_t st) {
-    const int v = a.image ? g_layer_variant : 0;  // the LDS variants need the prepared image
+    const int v = (a.image && g_layer_variant < 10) ? g_layer_variant : 0;  // the LDS variants need the prepared image
     if (L == 2 && v == 1) launch_k<H, L, INV, 2, true>(a, M, st);
     else if (L == 2 && v == 2) launch_k<H, L, INV, 1, true>(a, M, st);
     else if (L == 2 && v == 3) launch_k<H, L, INV, 1, false>(a, M, st);

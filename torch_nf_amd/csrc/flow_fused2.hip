@@ -3,6 +3,8 @@
 // contractions, and detected (not silent) f16 range overflow with an exact re-run of the affected tiles.
 // One launch per call: the workgroup's waves fold BatchNorm / Affine, pick the scales and build the layers'
 // operand images in LDS, then pull 32-sample groups from an LDS work queue.
+#include <type_traits>
+
 #include "f16_tile2.h"
 #include "tnf_common.h"
 
@@ -12,6 +14,24 @@
 #endif
 #ifndef TNF2_NW
 #define TNF2_NW 8   // waves per workgroup (one workgroup per CU: the operand images take most of the LDS)
+#endif
+#ifndef TNF2_RANGE_NT
+#define TNF2_RANGE_NT 2   // the layer-range kernel's tiles per wave iteration / waves per workgroup / workgroups per CU
+#endif
+#ifndef TNF2_RANGE_NW
+#define TNF2_RANGE_NW 8
+#endif
+#ifndef TNF2_RANGE_WGPC
+#define TNF2_RANGE_WGPC 1
+#endif
+#ifndef TNF2_RANGE_ABL
+#define TNF2_RANGE_ABL 0
+#endif
+#ifndef TNF2_RANGE_STAGE
+#define TNF2_RANGE_STAGE 1  // D = 64: rows enter and leave through an LDS staging area, 1 KB per wave instruction
+#endif
+#ifndef TNF2_RANGE_SWZ
+#define TNF2_RANGE_SWZ 1  // XOR-swizzle the staging area (conflict-free fragment reads)
 #endif
 #ifndef TNF2_UNROLL
 #define TNF2_UNROLL 1  // num_stages = 4: layer loop fully unrolled (every LDS operand offset an immediate)
@@ -275,6 +295,372 @@ flow_fused2_kernel(Flow2Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same tile code over a RANGE of coupling layers c_hi .. c_lo (walked downwards) per launch: the k = 2S design of
+// north_star (one fused kernel per coupling layer, z round-trips through HBM between them) and anything in between.
+// What crosses a launch boundary, per sample: the half the range's last layer transformed (true values), the running
+// log-det, and -- only when it is not in the buffer already -- that layer's conditioner half AS IT WAS BEFORE ITS FOLD:
+// the fold is owed to it and paid by the next launch, whose first layer transforms exactly that half (foldprev of
+// build_image2).  So an in-place middle launch reads 2 halves and writes 1: 392 B per sample instead of 520 at D = 64.
+// ---------------------------------------------------------------------------
+struct Range2Args {
+    Flow2Args f;
+    int c_hi, c_lo;       // layer range, 2S-1 >= c_hi >= c_lo >= 0
+    const float* ld_in;   // running log-det of the launches before (M, N), or NULL
+    int store_cond;       // non-final launches: also store the conditioner half of layer c_lo (before its fold)
+};
+
+template <int H, int L>
+__host__ __device__ constexpr int range2_lds_floats(int nr) {
+    // staging (waves x NT x 16 rows x D) | images (nr) | fold (nr + 1, 2, D) | fin (2 H) | kappa (nr ints, padded) |
+    // queue head (4) | red (16) | iv (7 D)
+    return TNF2_RANGE_NW * TNF2_RANGE_NT * 32 * H + nr * Img2<H, L>::FLOATS + (nr + 1) * 4 * H + 2 * H + ((nr + 3) / 4) * 4 +
+           4 + 16 + 7 * 2 * H;
+}
+
+__device__ __forceinline__ void fold_inverse(const Flow2Args& a, const float* prow, int D, int c, int d, float& A, float& B,
+                                             float& ld) {
+    const float alpha = a.bn_alpha[c * D + d], mu = a.bn_mean[c * D + d];
+    ld = -logf(alpha);
+    float ea = 1.f, shift = 0.f;
+    if (c & 1) {
+        const float* ap = prow + (c >> 1) * a.stage_stride + a.affine_off;
+        const float av = ap[d];
+        ld += av;
+        ea = expf(av);
+        shift = ap[D + d];
+    }
+    A = alpha / ea;
+    B = mu - shift * A;
+}
+
+// HI_FIRST / HI_LAST: layer c_hi / c_lo conditions on the upper half (c odd).  Compile-time, so that the two register
+// halves are never selected by a run-time index (that would put them in scratch memory).
+template <int H, int L, int NT, int NWAVES, bool HI_FIRST, bool HI_LAST>
+__global__ void __launch_bounds__(NWAVES * 64)
+flow_range2_kernel(Range2Args ra) {
+    constexpr int D = 2 * H;
+    constexpr int HT = H / 16;
+    typedef Img2<H, L> I;
+    const Flow2Args& a = ra.f;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nl = 2 * a.S;
+    const int c_hi = ra.c_hi, c_lo = ra.c_lo, nr = c_hi - c_lo + 1;
+    const int c_top = c_hi < nl - 1 ? c_hi + 1 : c_hi;  // folds are needed for c_lo .. c_top
+    const bool final_ = c_lo == 0;
+    float* stage = lds;                                // [NWAVES][NT * 16 rows][D]: wave-private staging of the rows in flight
+    float* img = lds + NWAVES * NT * 16 * D;           // [nr] image of layer c at index c - c_lo
+    float* fold = img + nr * I::FLOATS;                // [nr + 1][A (D) | B (D)], layer c at index c - c_lo
+    float* fin = fold + (nr + 1) * 2 * D;              // pending map of layer c_lo's conditioner half: [A (H) | B (H)]
+    int* kap = reinterpret_cast<int*>(fin + 2 * H);    // [nr]
+    int* qhead = kap + ((nr + 3) / 4) * 4;
+    float* red = reinterpret_cast<float*>(qhead + 4);  // [16]
+    float* ivc = red + 16;                             // [7][D]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    const int64_t m = grid_m();
+    if (m >= (a.Mz > a.Mp ? a.Mz : a.Mp)) return;
+    const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
+    const float* prow = a.params + mp * a.pstride;
+    const bool has_iv = a.iv != nullptr && c_hi == nl - 1;
+
+    {   // prologue A: folds of the range (+ the one owed from the launch before); the constant log-det on the last launch
+        for (int i = threadIdx.x; i < (c_top - c_lo + 1) * D; i += NWAVES * 64) {
+            const int ci = i / D, d = i - ci * D;
+            float A, B, ld;
+            fold_inverse(a, prow, D, c_lo + ci, d, A, B, ld);
+            fold[ci * 2 * D + d] = A;
+            fold[ci * 2 * D + D + d] = B;
+        }
+        float acc = 0.f;
+        if (final_)
+            for (int i = threadIdx.x; i < nl * D; i += NWAVES * 64) {
+                float A, B, ld;
+                fold_inverse(a, prow, D, i / D, i % D, A, B, ld);
+                acc += ld;
+            }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) red[wave] = acc;
+        if (threadIdx.x == 0) *qhead = NWAVES;
+        if (has_iv)
+            for (int i = threadIdx.x; i < 7 * D; i += NWAVES * 64) ivc[i] = a.iv[i];
+    }
+    __syncthreads();
+    for (int c = c_lo + wave; c <= c_hi; c += NWAVES) {
+        const int kc = layer_kappa<H>(prow + (c >> 1) * a.stage_stride + (c & 1) * a.low_off, a.U, lane,
+                                      fold + (c - c_lo) * 2 * D, c);
+        if (lane == 0) kap[c - c_lo] = kc;
+    }
+    __syncthreads();
+    for (int c = c_lo + wave; c <= c_hi; c += NWAVES) {
+        const float sc_in = pow2i(kap[c - c_lo]);
+        // the half layer c transforms arrives with the fold of the layer walked before it still owed (if there is one):
+        // inside the range that layer also scaled its registers, across a launch boundary it did not
+        const float* foldprev = c < nl - 1 ? fold + (c + 1 - c_lo) * 2 * D : nullptr;
+        const float sc_prev = c < c_hi ? pow2i(kap[c + 1 - c_lo]) : 1.f;
+        const float sig_next = c > c_lo ? pow2i(-kap[c - 1 - c_lo]) : 1.f;
+        build_image2<H, L>(img + (c - c_lo) * I::FLOATS, prow + (c >> 1) * a.stage_stride + (c & 1) * a.low_off, a.U, lane,
+                           fold + (c - c_lo) * 2 * D, foldprev, c, sc_in, sc_prev, sig_next);
+    }
+    {   // conditioner half of the range's last layer: true value = fin_A * register + fin_B; register * 2^kappa = what it
+        // was before that layer's fold
+        const int coff = (c_lo & 1) ? H : 0;
+        for (int f = threadIdx.x; f < H; f += NWAVES * 64) {
+            fin[f] = fold[coff + f] * pow2i(kap[0]);
+            fin[H + f] = fold[D + coff + f];
+        }
+    }
+    __syncthreads();
+
+    const float presc = pow2i(-kap[c_hi - c_lo]);
+    const float unsc = pow2i(kap[0]);
+    const float* zb = a.z + mz * a.N * D;
+    float* zo = a.z_out ? a.z_out + m * a.N * D : nullptr;
+    const float* ldi = ra.ld_in ? ra.ld_in + m * a.N : nullptr;
+    float* sldo = a.sum_log_det ? a.sum_log_det + m * a.N : nullptr;
+    float* lpo = (final_ && a.log_prob) ? a.log_prob + m * a.N : nullptr;
+    float ldc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) ldc += red[w];
+
+    const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
+    const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
+    const int64_t g_lo = (int64_t)blockIdx.x * per_block;
+    const int64_t g_hi = (g_lo + per_block < ngroups) ? g_lo + per_block : ngroups;
+    int64_t grp = g_lo + wave;
+    if (grp >= g_hi) return;
+
+    // ---- global <-> register traffic goes through a wave-private LDS staging area in WHOLE 1 KB pieces ----
+    // The MFMA lane mapping wants lane (s, q) to hold 16 bytes of row s: loaded straight from memory that is 16 rows x
+    // 64 B per wave instruction, and the layer kernel then streams at 3.8 TB/s; with 1 KB contiguous per instruction
+    // (four 256-B rows) the same kernel streams at 5.1 TB/s (measured with the arithmetic removed).  So a group of
+    // NT x 16 rows is loaded as it lies in memory, written to LDS as it lies (16-byte pieces XOR-swizzled by row so
+    // that the fragment reads are conflict-free), read back in fragment order; results take the same way out.
+    constexpr bool STAGED = (H == 32) && TNF2_RANGE_STAGE;  // 128-B rows (D = 32) stream as fast in fragment order
+    constexpr int GF = NT * 16 * D;         // floats per group
+    constexpr int NI = GF / 256;            // 1 KB wave instructions per group
+    constexpr int CPR = D / 4;              // 16-byte pieces per row
+    constexpr int RPB = (64 / CPR) > 0 ? (64 / CPR) : 1;  // rows per 256-B bank row
+    float* stg = stage + wave * GF;
+    auto sw_off = [&](int r, int ch) -> int {  // float offset of piece ch of row r inside the staging area
+#if TNF2_RANGE_SWZ
+        return r * D + ((ch ^ ((r / RPB) & (CPR - 1))) << 2);
+#else
+        return r * D + (ch << 2);
+#endif
+    };
+    auto load_raw = [&](int64_t g, f4 (&raw)[NI], float (&ldp)[NT]) {
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int off = k * 256 + lane * 4;
+                int64_t row = g * (NT * 16) + off / D;
+                if (row >= a.N) row = a.N - 1;
+                raw[k] = *reinterpret_cast<const f4*>(zb + row * D + (off % D));
+            }
+        } else {  // fragment order straight from memory: raw[(t, half, mm)]
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int64_t row = (g * NT + t) * 16 + s;
+                if (row >= a.N) row = a.N - 1;
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm) {
+                    raw[(t * 2 + 0) * HT + mm] = *reinterpret_cast<const f4*>(zb + row * D + 16 * mm + 4 * q);
+                    raw[(t * 2 + 1) * HT + mm] = *reinterpret_cast<const f4*>(zb + row * D + H + 16 * mm + 4 * q);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int64_t row = (g * NT + t) * 16 + s;
+            if (row >= a.N) row = a.N - 1;
+            ldp[t] = ldi ? ldi[row] : 0.f;
+        }
+    };
+    auto unstage = [&](const f4 (&raw)[NI], f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT]) {
+        if constexpr (!STAGED) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm) {
+                    dlo[t][mm] = raw[(t * 2 + 0) * HT + mm];
+                    dhi[t][mm] = raw[(t * 2 + 1) * HT + mm];
+                }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int off = k * 256 + lane * 4;
+            *reinterpret_cast<f4*>(stg + sw_off(off / D, (off % D) >> 2)) = raw[k];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                dlo[t][mm] = *reinterpret_cast<const f4*>(stg + sw_off(16 * t + s, 4 * mm + q));
+                dhi[t][mm] = *reinterpret_cast<const f4*>(stg + sw_off(16 * t + s, H / 4 + 4 * mm + q));
+            }
+    };
+    auto enter = [&](f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssup)[NT]) {
+        if (has_iv) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float o, l;
+                        interval_fast<true>(dlo[t][mm][j], ivc, D, 16 * mm + 4 * q + j, o, l);
+                        dlo[t][mm][j] = o;
+                        ssup[t] += l;
+                        interval_fast<true>(dhi[t][mm][j], ivc, D, H + 16 * mm + 4 * q + j, o, l);
+                        dhi[t][mm][j] = o;
+                        ssup[t] += l;
+                    }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (HI_FIRST) dhi[t][mm][j] *= presc;
+                    else dlo[t][mm][j] *= presc;
+                }
+    };
+    auto layers = [&](auto slow, f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssum)[NT]) {
+        for (int c = c_hi; c >= c_lo; --c) {
+            const float* im = img + (c - c_lo) * I::FLOATS;
+            if (c & 1) coupling_tile2<H, L, NT, decltype(slow)::value>(im, lane, dhi, dlo, ssum);
+            else coupling_tile2<H, L, NT, decltype(slow)::value>(im, lane, dlo, dhi, ssum);
+        }
+    };
+
+    f4 raw[NI];
+    float nld[NT];
+    load_raw(grp, raw, nld);
+
+    for (;;) {
+        int nxt_off = 0;
+        if (lane == 0) nxt_off = atomicAdd(qhead, 1);
+        const int64_t nxt = g_lo + __builtin_amdgcn_readfirstlane(nxt_off);
+        const bool has_next = nxt < g_hi;
+        f4 lo[NT][HT], hi[NT][HT];
+        float ssum[NT], ssup[NT], ldp[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            ssum[t] = 0.f;
+            ssup[t] = 0.f;
+            ldp[t] = nld[t];
+        }
+        unstage(raw, lo, hi);
+        enter(lo, hi, ssup);
+        if (has_next) load_raw(nxt, raw, nld);
+#if TNF2_RANGE_ABL == 0  // (1, 2 = timing experiments: loads and stores only)
+        layers(std::false_type{}, lo, hi, ssum);
+#endif
+        float chk = ssum[0];
+#pragma unroll
+        for (int t = 1; t < NT; ++t) chk += ssum[t];
+        if (__builtin_expect(__any(chk != chk), 0)) {  // out-of-range input: exact first-layer contractions (f16_tile2.h)
+            {
+                f4 again[NI];  // (the prefetch of the next group stays in `raw`)
+                load_raw(grp, again, ldp);
+                unstage(again, lo, hi);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                ssum[t] = 0.f;
+                ssup[t] = 0.f;
+            }
+            enter(lo, hi, ssup);
+            layers(std::true_type{}, lo, hi, ssum);
+            if (a.slow_count && lane == 0) atomicAdd(a.slow_count, 1u);
+        }
+        // conditioner half of the last layer: true values on the final launch, its pre-fold values otherwise
+#pragma unroll
+        for (int mm = 0; mm < HT; ++mm) {
+            const f4 fa = *reinterpret_cast<const f4*>(fin + 16 * mm + 4 * q);
+            const f4 fb = *reinterpret_cast<const f4*>(fin + H + 16 * mm + 4 * q);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (HI_LAST) hi[t][mm][j] = final_ ? __builtin_fmaf(hi[t][mm][j], fa[j], fb[j]) : hi[t][mm][j] * unsc;
+                    else lo[t][mm][j] = final_ ? __builtin_fmaf(lo[t][mm][j], fa[j], fb[j]) : lo[t][mm][j] * unsc;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t row = (grp * NT + t) * 16 + s;
+            const bool row_ok = row < a.N;
+            float ld_tot = __builtin_fmaf(reduce_q(ssum[t]), kLn2, ldp[t]) + (has_iv ? reduce_q(ssup[t]) : 0.f);
+            if (final_) ld_tot += ldc;
+            if (lpo) {
+                float sq = 0.f;
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sq = __builtin_fmaf(lo[t][mm][j], lo[t][mm][j], sq);
+                        sq = __builtin_fmaf(hi[t][mm][j], hi[t][mm][j], sq);
+                    }
+                sq = reduce_q(sq);
+                if (q == 0 && row_ok) lpo[row] = -0.5f * sq - (float)D * 0.91893853320467274178f - ld_tot;
+            }
+            if (sldo && q == 0 && row_ok) sldo[row] = ld_tot;
+        }
+        if (zo && !STAGED) {
+            const bool st_lo = final_ || HI_LAST || ra.store_cond, st_hi = final_ || !HI_LAST || ra.store_cond;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int64_t row = (grp * NT + t) * 16 + s;
+                if (row < a.N) {
+                    float* zr = zo + row * D + 4 * q;
+#pragma unroll
+                    for (int mm = 0; mm < HT; ++mm) {
+                        if (st_lo) *reinterpret_cast<f4*>(zr + 16 * mm) = lo[t][mm];
+                        if (st_hi) *reinterpret_cast<f4*>(zr + H + 16 * mm) = hi[t][mm];
+                    }
+                }
+            }
+        }
+        if (zo && STAGED) {  // results leave through the staging area: whole 128-byte lines per row and instruction
+            const bool st_lo = final_ || HI_LAST || ra.store_cond, st_hi = final_ || !HI_LAST || ra.store_cond;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm) {
+                    if (st_lo) *reinterpret_cast<f4*>(stg + sw_off(16 * t + s, 4 * mm + q)) = lo[t][mm];
+                    if (st_hi) *reinterpret_cast<f4*>(stg + sw_off(16 * t + s, H / 4 + 4 * mm + q)) = hi[t][mm];
+                }
+            const int64_t row0 = grp * (NT * 16);
+            if (st_lo && st_hi) {
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const int off = k * 256 + lane * 4;
+                    const int r = off / D;
+                    const f4 v = *reinterpret_cast<const f4*>(stg + sw_off(r, (off % D) >> 2));
+                    if (row0 + r < a.N) *reinterpret_cast<f4*>(zo + (row0 + r) * D + (off % D)) = v;
+                }
+            } else {
+                constexpr int LPR = H / 4, RPI = 64 / LPR;  // lanes per half row, half rows per instruction
+                const int hoff = st_hi ? H : 0;
+#pragma unroll
+                for (int k = 0; k < NT * 16 / RPI; ++k) {
+                    const int r = k * RPI + lane / LPR, ch = (hoff >> 2) + lane % LPR;
+                    const f4 v = *reinterpret_cast<const f4*>(stg + sw_off(r, ch));
+                    if (row0 + r < a.N) *reinterpret_cast<f4*>(zo + (row0 + r) * D + (ch << 2)) = v;
+                }
+            }
+        }
+        if (!has_next) break;
+        grp = nxt;
+    }
+}
+
 template <int H, int L>
 static size_t flow2_lds_bytes(int S) {
     return (size_t)flow2_lds_floats<H, L>(2 * S) * sizeof(float);
@@ -328,6 +714,64 @@ int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log
     else rc = L == 1 ? launch2_v<16, 1>(a, M, st) : (L == 2 ? launch2_v<16, 2>(a, M, st) : launch2_v<16, 3>(a, M, st));
     if (rc != TNF_OK) return rc;
     return check_launch("flow_fused2");
+}
+
+
+template <int H, int L>
+static int launch_range_t(const Range2Args& ra, int64_t M, hipStream_t st) {
+    constexpr int NT = TNF2_RANGE_NT, NW = TNF2_RANGE_NW;
+    const size_t smem = (size_t)range2_lds_floats<H, L>(ra.c_hi - ra.c_lo + 1) * sizeof(float);
+    const bool hf = (ra.c_hi & 1) != 0, hl = (ra.c_lo & 1) != 0;
+    auto kern = hf ? (hl ? flow_range2_kernel<H, L, NT, NW, true, true> : flow_range2_kernel<H, L, NT, NW, true, false>)
+                   : (hl ? flow_range2_kernel<H, L, NT, NW, false, true> : flow_range2_kernel<H, L, NT, NW, false, false>);
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return fail(TNF_ELAUNCH, "flow_range2: cannot reserve %zu B of LDS", smem);
+    const int64_t ngroups = (ra.f.N + 16 * NT - 1) / (16 * NT);
+    int64_t bx = (ngroups + NW - 1) / NW;
+    int64_t cap = (256 * TNF2_RANGE_WGPC + M - 1) / M;  // registers allow one 8-wave workgroup per CU
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(NW * 64), smem, st, ra);
+    return TNF_OK;
+}
+
+bool flow_range2_supported(int D, int L, int U, int nlayers) {
+    if (!mfma_supported(D, L, U) || nlayers < 1) return false;
+    const size_t b = (D == 64) ? (L == 1 ? range2_lds_floats<32, 1>(nlayers) : (L == 2 ? range2_lds_floats<32, 2>(nlayers) : range2_lds_floats<32, 3>(nlayers)))
+                               : (L == 1 ? range2_lds_floats<16, 1>(nlayers) : (L == 2 ? range2_lds_floats<16, 2>(nlayers) : range2_lds_floats<16, 3>(nlayers)));
+    return b * sizeof(float) <= 160 * 1024;
+}
+
+// NormFlow.log_prob / inverse_and_log_det as a CHAIN of launches, `per_launch` coupling layers each (1 = the k = 2S design).
+// zbuf (M, N, D) and ldbuf (M, N): caller-owned scratch (zbuf may be z0, ldbuf may be sum_log_det).
+int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, float* sum_log_det, float* log_prob, int64_t Mz,
+                       int64_t Mp, int64_t N, int D, int S, int L, int U, const float* params, int64_t pstride,
+                       const float* bn_mean, const float* bn_alpha, const float* interval_consts, unsigned* slow_count,
+                       int per_launch, hipStream_t st) {
+    const int nl = 2 * S;
+    if (per_launch < 1) per_launch = 1;
+    if (!flow_range2_supported(D, L, U, per_launch))
+        return fail(TNF_EUNSUPPORTED, "flow_chain2: no kernel for D=%d L=%d U=%d with %d layers per launch", D, L, U, per_launch);
+    if (N <= 0) return TNF_OK;
+    const int64_t M = Mz > Mp ? Mz : Mp;
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    for (int c_hi = nl - 1; c_hi >= 0; c_hi -= per_launch) {
+        const int c_lo = c_hi - per_launch + 1 > 0 ? c_hi - per_launch + 1 : 0;
+        const bool first = c_hi == nl - 1, last = c_lo == 0;
+        Range2Args ra;
+        ra.f = Flow2Args{first ? z : zbuf, last ? z0 : zbuf, last ? sum_log_det : ldbuf, last ? log_prob : nullptr,
+                         first ? Mz : M, Mp, N, S, U, params, bn_mean, bn_alpha, pstride, fl.stage, fl.p_up + fl.p_low, fl.p_up,
+                         interval_consts, slow_count};
+        ra.c_hi = c_hi;
+        ra.c_lo = c_lo;
+        ra.ld_in = first ? nullptr : ldbuf;
+        // the conditioner half of the range's last layer must be written unless it is in zbuf already: a later launch of
+        // ONE layer did not touch it (with more layers per launch the layer before transformed it inside the launch)
+        ra.store_cond = (first || c_hi > c_lo) ? 1 : 0;
+        int rc = (D == 64) ? (L == 1 ? launch_range_t<32, 1>(ra, M, st) : (L == 2 ? launch_range_t<32, 2>(ra, M, st) : launch_range_t<32, 3>(ra, M, st)))
+                           : (L == 1 ? launch_range_t<16, 1>(ra, M, st) : (L == 2 ? launch_range_t<16, 2>(ra, M, st) : launch_range_t<16, 3>(ra, M, st)));
+        if (rc != TNF_OK) return rc;
+    }
+    return check_launch("flow_chain2");
 }
 
 }  // namespace tnf

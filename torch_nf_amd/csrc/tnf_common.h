@@ -98,6 +98,8 @@ struct MfmaLayerArgs {
     int64_t Mz, Mp, N;
     int D, L, U, upper, inverse;
     int wave_m;  // set by the launcher: one context (m) per wave instead of per workgroup (many contexts, few samples)
+    int skip_cond_store;  // in-place chains (z_out == z): leave the conditioner half in memory as it is -- the fold this
+                          // kernel applied to it is composed into the next kernel's constants (flow_fold_kernel, chain = 1)
 };
 int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st);
 
@@ -116,7 +118,7 @@ int launch_flow_fold_backward(const float* params, const float* bn_alpha, const 
                               int64_t gpstride, hipStream_t st);
 int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_alpha, float* fold,
                      float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
-                     int64_t pstride, int inverse, hipStream_t st);
+                     int64_t pstride, int inverse, hipStream_t st, int chain = 0);
 
 int launch_flow_fused(const float* z, const float* images, const float* fold, const float* ldc,
                       float* z_out, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp,
@@ -127,6 +129,12 @@ bool flow_fused2_supported(int D, int S, int L, int U);
 int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
                        int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
                        const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st);
+// the same tile code as a chain of launches with `per_launch` coupling layers each (1 = one kernel per coupling layer)
+bool flow_range2_supported(int D, int L, int U, int nlayers);
+int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, float* sum_log_det, float* log_prob, int64_t Mz,
+                       int64_t Mp, int64_t N, int D, int S, int L, int U, const float* params, int64_t pstride,
+                       const float* bn_mean, const float* bn_alpha, const float* interval_consts, unsigned* slow_count,
+                       int per_launch, hipStream_t st);
 // split-f16 variant of the whole-flow kernel (flow_fused_f16.hip); images in slots of mfma_image_floats(D, 3)
 int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,
                            int64_t pstride, hipStream_t st);
