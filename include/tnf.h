@@ -423,10 +423,18 @@ int tnf_flow_forward_train_bwd_f32(const float* omega, const float* params, cons
  * accumulate).  g_z may be NULL when the gradient w.r.t. z is not wanted; g_params as above
  * (accumulated, zero it first).  BatchNorm statistics are constants.  Available when
  * tnf_flow_train_rev_supported() is 1 (D in {32, 64}, num_units <= 16, the layers' gradient
- * accumulators fit the 160 KB LDS). */
+ * accumulators fit the 160 KB LDS).
+ * The parameter gradient is REPRODUCIBLE bit for bit (like the reference's CPU loop,
+ * notebooks/LFI_learning_rules.ipynb:295-304): workgroups accumulate in 32-bit fixed point (integer adds commute)
+ * and store their partial rows; a second kernel adds the rows in block order in 64-bit integers.
+ * `overflow` (device int32, may be NULL): set to 1 when a gradient term exceeded the fixed-point budget (2^13 in units
+ * where max |g_log_prob| is in [1, 2): a heavy-tailed sample whose deltas also approach the f16 range of the
+ * split operands) -- the returned g_params rows are then NaN, never a wrapped sum, and the caller re-runs the step
+ * through tnf_flow_log_prob_fwd_f32 / _bwd_f32 with fp32 layer kernels (TNF_OPT_TRAIN_BWD_FP32), which have no such
+ * budget; torch_nf_amd.ops does exactly that. */
 int tnf_flow_train_rev_supported(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units);
-int64_t tnf_flow_train_rev_workspace_bytes(int64_t M_p, int32_t D, int32_t num_stages, int32_t num_layers,
-                                           int32_t num_units);
+int64_t tnf_flow_train_rev_workspace_bytes(int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t num_stages,
+                                           int32_t num_layers, int32_t num_units);
 int tnf_flow_log_prob_fwd_rev_f32(const float* z, const float* params, const float* bn_mean, const float* bn_alpha,
                                   float* log_prob, float* z0, int64_t M, int64_t M_p, int64_t N, int32_t D,
                                   int32_t num_stages, int32_t num_layers, int32_t num_units,
@@ -435,7 +443,7 @@ int tnf_flow_log_prob_bwd_rev_f32(const float* z0, const float* params, const fl
                                   const float* g_log_prob, float* g_z, float* g_params, int64_t M, int64_t M_p,
                                   int64_t N, int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units,
                                   int64_t params_row_stride, int64_t g_params_row_stride, void* workspace,
-                                  int64_t workspace_bytes, void* stream);
+                                  int64_t workspace_bytes, int32_t* overflow, void* stream);
 
 /* The deterministic part of NormFlow.forward with freeze_bn=True
  * (density_estimator.py:374-388): pushes base samples `omega` (M,N,D) through

@@ -130,8 +130,11 @@ def test_training_entries_host_side():
     assert lib.tnf_flow_train_rev_supported(64, 4, 2, 15) == 1 and lib.tnf_flow_train_rev_supported(32, 4, 3, 16) == 1
     assert lib.tnf_flow_train_rev_supported(64, 5, 2, 15) == 0 and lib.tnf_flow_train_rev_supported(64, 4, 3, 15) == 0
     assert lib.tnf_flow_train_rev_supported(8, 2, 2, 15) == 0 and lib.tnf_flow_train_rev_supported(64, 4, 2, 17) == 0
-    w1, w4 = lib.tnf_flow_train_rev_workspace_bytes(1, 64, 4, 2, 15), lib.tnf_flow_train_rev_workspace_bytes(4, 64, 4, 2, 15)
-    assert 0 < w1 < w4 and lib.tnf_flow_train_rev_workspace_bytes(1, 64, 5, 2, 15) < 0
+    w1 = lib.tnf_flow_train_rev_workspace_bytes(1, 1, 4096, 64, 4, 2, 15)
+    w4 = lib.tnf_flow_train_rev_workspace_bytes(4, 4, 4096, 64, 4, 2, 15)
+    assert 0 < w1 < w4 and lib.tnf_flow_train_rev_workspace_bytes(1, 1, 4096, 64, 5, 2, 15) < 0
+    # the deterministic reduction keeps one partial gradient row per workgroup: 256 of them at the benchmark size
+    assert lib.tnf_flow_train_rev_workspace_bytes(1, 1, 1 << 19, 64, 4, 2, 15) >= 256 * 8 * (2494 + 128) * 4
     # AR one-kernel backward: the MFMA MAF backward's shapes
     assert lib.tnf_ar_flow_train_supported(6, 2, 15) == 1 and lib.tnf_ar_flow_train_supported(21, 2, 42) == 1
     assert lib.tnf_ar_flow_train_supported(33, 2, 15) == 0 and lib.tnf_ar_flow_train_supported(6, 4, 15) == 0
@@ -144,7 +147,7 @@ def test_training_entries_host_side():
     EINVAL, EUNSUP = -1, -2
     n = None
     assert lib.tnf_flow_log_prob_fwd_rev_f32(n, n, n, n, n, n, 1, 1, 16, 8, 2, 2, 15, 100000, n) == EUNSUP
-    assert lib.tnf_flow_log_prob_bwd_rev_f32(n, n, n, n, n, n, n, 2, 3, 16, 64, 4, 2, 15, 100000, 100000, n, 0, n) == EINVAL
+    assert lib.tnf_flow_log_prob_bwd_rev_f32(n, n, n, n, n, n, n, 2, 3, 16, 64, 4, 2, 15, 100000, 100000, n, 0, n, n) == EINVAL
     assert lib.tnf_ar_flow_log_prob_bwd_f32(n, n, n, n, n, n, n, n, 1, 1, 16, 40, 2, 15, 100000, 100000, n, 0, n) == EUNSUP
     assert lib.tnf_flow_forward_batch_f32(n, n, n, n, n, n, 1, 1, 1, 64, 4, 2, 15, 100000, 1e-5, n, 0, n) == EINVAL  # one row
     assert lib.tnf_flow_forward_train_bwd_f32(n, n, n, n, n, n, n, n, n, n, 1, 1, 64, 8, 2, 2, 15, 100000, 100000, n, 0, n) == EUNSUP

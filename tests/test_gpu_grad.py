@@ -374,3 +374,69 @@ def test_training_step_full_size_properties(tnf):
     assert float((g_l16 - g_l32).abs().max()) <= 2e-5 * top
     a = 0.37 / 1024.0
     assert float((grad(True, 0, a) / a - g_rev).abs().max()) <= 2e-5 * top
+
+
+@pytest.mark.parametrize("M,Mp,N", [(1, 1, 1 << 17), (3, 1, 5000), (4, 4, 3000)])
+def test_flow_reversible_backward_is_reproducible(tnf, M, Mp, N):
+    """The parameter gradient of the reversible pair is bit-for-bit reproducible, like the reference's CPU training loop
+    (notebooks/LFI_learning_rules.ipynb:295-304): workgroups accumulate in 32-bit fixed point and a second kernel adds
+    their partial rows in block order -- no floating-point atomics anywhere between the samples and g_params."""
+    D, S, L, U = 64, 4, 2, 15
+    rng = np.random.RandomState(N)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.1, (Mp, nf.D_params))).float().cuda()
+    z = torch.randn(M, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    w = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(8))
+    grads = []
+    for _ in range(3):
+        p = p0.clone().requires_grad_()
+        assert nf._train_path(z, p) == "reversible"
+        ((nf.log_prob(z, p) * w).sum() / N).backward()
+        grads.append(p.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    assert bool(torch.isfinite(grads[0]).all()) and float(grads[0].abs().max()) > 0
+
+
+def test_flow_reversible_backward_overflow_falls_back(tnf, oracle):
+    """A gradient term beyond the fixed-point budget of the one-kernel backward (here: a handful of samples 3000 sigma
+    out, whose -g z0 seeds are ~1e4 times everyone else's) is flagged by the kernel -- its own result is NaN, not a
+    wrapped sum -- and ops.flow_log_prob_train recomputes the step through the per-layer pair with fp32 layer kernels:
+    the gradient the caller sees matches torch autograd over the oracle."""
+    D, S, L, U, N = 64, 4, 2, 15, 4096
+    rng = np.random.RandomState(1)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.05, (1, nf.D_params))).float()
+    stats = [(torch.zeros(D), torch.ones(D))] * (2 * S)
+    z0 = torch.tensor(rng.normal(0, 1, (1, N, D))).float()
+    z0[0, ::512] *= 3000.0
+    p_ref = p0.clone().requires_grad_()
+    (-oracle.flow_log_prob(z0, p_ref, D, S, L, U, stats).sum()).backward()
+    fn = tnf.ops._FlowLogProbRevFn
+    before = fn.overflow_fallbacks
+    p = p0.cuda().requires_grad_()
+    z = z0.cuda()
+    assert nf._train_path(z, p) == "reversible"
+    (-nf.log_prob(z, p).sum()).backward()
+    assert fn.overflow_fallbacks == before + 1, "the fixed-point budget must have been exceeded by this input"
+    assert bool(torch.isfinite(p.grad).all())
+    scale = float(p_ref.grad.abs().max())
+    torch.testing.assert_close(p.grad.cpu() / scale, p_ref.grad / scale, rtol=2e-3, atol=2e-5)
+    # ... and the raw C call alone reports the overflow and poisons its rows instead of returning a wrapped sum
+    lib, L_ = tnf._lib.lib, tnf._lib
+    mean, alpha = nf._bn_stats(torch.device("cuda"))
+    lp = torch.empty(1, N, device="cuda")
+    zz = torch.empty_like(z)
+    pc = p0.cuda()
+    L_.check(lib.tnf_flow_log_prob_fwd_rev_f32(z.data_ptr(), pc.data_ptr(), mean.data_ptr(), alpha.data_ptr(), lp.data_ptr(),
+                                               zz.data_ptr(), 1, 1, N, D, S, L, U, pc.shape[1], L_.stream_ptr()))
+    for src, want_flag in ((zz, 1), (torch.randn_like(zz), 0)):
+        g = -torch.ones(1, N, device="cuda")
+        gp = torch.zeros_like(pc)
+        nbytes = L_.check(lib.tnf_flow_train_rev_workspace_bytes(1, 1, N, D, S, L, U))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        flag = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+        L_.check(lib.tnf_flow_log_prob_bwd_rev_f32(src.data_ptr(), pc.data_ptr(), mean.data_ptr(), alpha.data_ptr(),
+                                                   g.data_ptr(), None, gp.data_ptr(), 1, 1, N, D, S, L, U, pc.shape[1],
+                                                   gp.shape[1], ws.data_ptr(), nbytes, flag.data_ptr(), L_.stream_ptr()))
+        assert int(flag.item()) == want_flag
+        assert bool(torch.isnan(gp).any()) == bool(want_flag), (want_flag, int(torch.isnan(gp).sum()), gp.numel())

@@ -100,11 +100,11 @@ SIGNATURES = {
     "tnf_ar_flow_log_prob_bwd_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
                                                     _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
     "tnf_flow_train_rev_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
-    "tnf_flow_train_rev_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32]),
+    "tnf_flow_train_rev_workspace_bytes": (_i64, [_i64, _i64, _i64, _i32, _i32, _i32, _i32]),
     "tnf_flow_log_prob_fwd_rev_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                                      _i32, _i32, _i64, _vp]),
     "tnf_flow_log_prob_bwd_rev_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
-                                                     _i32, _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
+                                                     _i32, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tnf_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                             _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
 }

@@ -885,11 +885,13 @@ int tnf_flow_train_rev_supported(int32_t D, int32_t S, int32_t L, int32_t U) {
     return (flow_fused_supported(D, S, L, U) && flow_train_rev_supported(D, S, L, U)) ? 1 : 0;
 }
 
-int64_t tnf_flow_train_rev_workspace_bytes(int64_t M_p, int32_t D, int32_t S, int32_t L, int32_t U) {
-    if (M_p < 1) return fail(TNF_EINVAL, "tnf_flow_train_rev_workspace_bytes: M_p=%lld", (long long)M_p);
+int64_t tnf_flow_train_rev_workspace_bytes(int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U) {
+    if (M < 1 || (M_p != 1 && M_p != M) || N < 0)
+        return fail(TNF_EINVAL, "tnf_flow_train_rev_workspace_bytes: M=%lld M_p=%lld N=%lld", (long long)M, (long long)M_p,
+                    (long long)N);
     if (!tnf_flow_train_rev_supported(D, S, L, U))
         return fail(TNF_EUNSUPPORTED, "tnf_flow_train_rev_workspace_bytes: D=%d S=%d L=%d U=%d", D, S, L, U);
-    return flow_train_rev_workspace(M_p, D, S, L);
+    return flow_train_rev_workspace(M, M_p, N, D, S, L, U);
 }
 
 static int rev_checks(const char* fn, int64_t M, int64_t M_p, int64_t N, int D, int S, int L, int U, int64_t pstride) {
@@ -923,7 +925,8 @@ int tnf_flow_log_prob_fwd_rev_f32(const float* z, const float* params, const flo
 int tnf_flow_log_prob_bwd_rev_f32(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
                                   const float* g_log_prob, float* g_z, float* g_params, int64_t M, int64_t M_p,
                                   int64_t N, int32_t D, int32_t S, int32_t L, int32_t U, int64_t pstride,
-                                  int64_t gpstride, void* workspace, int64_t workspace_bytes, void* stream) {
+                                  int64_t gpstride, void* workspace, int64_t workspace_bytes, int32_t* overflow,
+                                  void* stream) {
     int rc = rev_checks("tnf_flow_log_prob_bwd_rev_f32", M, M_p, N, D, S, L, U, pstride);
     if (rc) return rc;
     if (N == 0) return TNF_OK;
@@ -933,11 +936,11 @@ int tnf_flow_log_prob_bwd_rev_f32(const float* z0, const float* params, const fl
         return fail(TNF_EINVAL, "tnf_flow_log_prob_bwd_rev_f32: z0 / g_z must be 16-byte aligned");
     if (gpstride < flow_layout(D, S, L, U).total)
         return fail(TNF_EINVAL, "tnf_flow_log_prob_bwd_rev_f32: g_params row too short");
-    if (!workspace || workspace_bytes < flow_train_rev_workspace(M_p, D, S, L))
+    if (!workspace || workspace_bytes < flow_train_rev_workspace(M, M_p, N, D, S, L, U))
         return fail(TNF_EWORKSPACE, "tnf_flow_log_prob_bwd_rev_f32: workspace %lld < %lld", (long long)workspace_bytes,
-                    (long long)flow_train_rev_workspace(M_p, D, S, L));
+                    (long long)flow_train_rev_workspace(M, M_p, N, D, S, L, U));
     return launch_flow_bwd_rev(z0, params, bn_mean, bn_alpha, g_log_prob, g_z, g_params, M, M_p, N, D, S, L, U, pstride,
-                               gpstride, workspace, as_stream(stream));
+                               gpstride, workspace, overflow, as_stream(stream));
 }
 
 // NormFlow.forward with batch-statistics BatchNorm (freeze_bn=False), no autograd: one C call for the whole stack

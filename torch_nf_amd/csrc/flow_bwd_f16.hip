@@ -328,6 +328,12 @@ struct FlowBwdArgs {
     int64_t M, Mp, N, gpstride, stage, low_off;
     int S, U;
     float fx;            // fixed-point scale of the LDS accumulators
+    // deterministic cross-workgroup reduction: every workgroup stores its fixed-point accumulators (plain stores) as
+    // row `block` of partials (nblocks, prow) and its sum of g_log_prob into glp_part[block]; flow_bwd_reduce_kernel
+    // adds the rows in block order.  NULL: a workgroup owns its gradient row alone and writes it directly.
+    int* partials;
+    float* glp_part;
+    int* overflow;       // set to 1 when a fixed-point accumulator may have wrapped (the gradient rows are NaN then)
 };
 
 // One coupling layer backwards on one tile.  x: conditioner half (= layer input and output);
@@ -659,6 +665,54 @@ __device__ __forceinline__ void unfold_half(const float* fc, int* gf, FxAcc& fa,
     }
 }
 
+// Second pass of the deterministic reduction: gradient row mp = sum over its nred workgroups' fixed-point rows, in
+// block order, in 64-bit integers (exact, so the order would not even matter), scaled back once.  A wrapped
+// accumulator anywhere (*overflow) poisons the rows with NaN instead: never a wrong finite gradient.
+__global__ void __launch_bounds__(256)
+flow_bwd_reduce_kernel(const int* __restrict__ partials, const float* __restrict__ glp_part, const unsigned* __restrict__ gmax,
+                       const int* __restrict__ overflow, float* __restrict__ g_params, float* __restrict__ g_fold,
+                       float* __restrict__ glp_sum, int64_t nred, int nl, int P, int D, int64_t gpstride, int64_t stage,
+                       int64_t low_off, float fx) {
+    const int64_t mp = blockIdx.y;
+    const int64_t prow = (int64_t)nl * (P + 2 * D);
+    float isc = 1.f;
+    {
+        const float gm = __uint_as_float(*gmax);
+        if (gm > 0.f && gm < 3.0e38f) {
+            int e;
+            (void)frexpf(gm, &e);
+            int k = 1 - e;
+            k = k > 120 ? 120 : (k < -120 ? -120 : k);
+            isc = ldexpf(1.f, -k);
+        }
+    }
+    const float unfx = isc / fx;
+    const float poison = *overflow ? __builtin_nanf("") : 0.f;
+    const int* src = partials + mp * nred * prow;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < prow; i += (int64_t)gridDim.x * 256) {
+        long long acc = 0;
+        int64_t b = 0;
+        for (; b + 8 <= nred; b += 8) {  // eight rows in flight
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(b + u) * prow + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (long long)v[u];
+        }
+        for (; b < nred; ++b) acc += (long long)src[b * prow + i];
+        const int c = (int)(i / (P + 2 * D));
+        const int k = (int)(i - (int64_t)c * (P + 2 * D));
+        const float v = (float)acc * unfx + poison;
+        if (k < P) g_params[mp * gpstride + (c >> 1) * stage + ((c & 1) ? low_off : 0) + k] += v;
+        else if (c & 1) g_fold[(mp * nl + c) * 2 * D + (k - P)] += v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int64_t bb = 0; bb < nred; ++bb) t += glp_part[mp * nred + bb];
+        glp_sum[mp] += t;
+    }
+}
+
 template <int H, int L, int NW, bool SPARE>
 __global__ void __launch_bounds__(NW * 64)
 flow_bwd_f16_kernel(FlowBwdArgs a) {
@@ -787,9 +841,9 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
         }
     }
 
-    // ---- flush: one global atomic per parameter per workgroup ----
-    // a term above the fixed-point budget may have wrapped an accumulator: poison the result instead of
-    // returning a wrong gradient (the budget is 2^13 per term in units where max |g_log_prob| is 1..2)
+    // ---- flush ----
+    // a term above the fixed-point budget may have wrapped an accumulator: flag it (the reduction then poisons the
+    // result instead of returning a wrong gradient; the budget is 2^13 per term in units where max |g_log_prob| is 1..2)
     float amax = fa.amax;
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
     float* red = scr;  // the transposition scratch is free now
@@ -798,34 +852,36 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < NW; ++w) amax = fmaxf(amax, red[w]);
-    const float poison = (amax * (float)(iters * NW) >= 2147483648.f) ? __builtin_nanf("") : 0.f;
-    const float unfx = isc / a.fx;
-    float* gp = a.g_params + mp * a.gpstride;
-    float* gfo = a.g_fold + mp * (int64_t)nl * 2 * D;
-    // walk the layer's parameter block (bijectors.py:222-235: per MLP layer [W_t | W_s | b_t | b_s], W[in][out])
+    const bool wrapped = !(amax * (float)(iters * NW) < 2147483648.f);  // (also true for NaN / inf terms)
+    if (wrapped && threadIdx.x == 0) atomicOr(a.overflow, 1);
     const int P = 2 * (H * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
-    for (int i = threadIdx.x; i < nl * (P + 2 * D); i += NW * 64) {
-        const int c = i / (P + 2 * D);
-        int k = i - c * (P + 2 * D);
-        const int* acc = accb + c * ACC;
-        int src;
-        if (k >= P) {
-            if (!(c & 1)) continue;
-            src = A_::o_fold + (k - P);
-        } else {
-            src = acc_src<H, L, SPARE>(k, U);
-        }
-        const float v = (float)acc[src] * unfx + poison;
-        if (k < P) atomicAdd(gp + (c >> 1) * a.stage + ((c & 1) ? a.low_off : 0) + k, v);
-        else atomicAdd(gfo + (int64_t)c * 2 * D + (k - P), v);
-    }
+    float tot = glp_acc;
+    tot += __shfl_xor(tot, 1);
+    tot += __shfl_xor(tot, 2);
+    tot += __shfl_xor(tot, 4);
+    tot += __shfl_xor(tot, 8);  // lanes 0..15 (q = 0) carried the terms
+    __syncthreads();
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
     {
-        float tot = glp_acc;
-        tot += __shfl_xor(tot, 1);
-        tot += __shfl_xor(tot, 2);
-        tot += __shfl_xor(tot, 4);
-        tot += __shfl_xor(tot, 8);
-        if (lane == 0) atomicAdd(a.glp_sum + mp, tot * isc);
+        // this workgroup's fixed-point contribution, in the order of the gradient row: layer c -> [parameter block (P) |
+        // fold (2 D)]; flow_bwd_reduce_kernel adds the rows up
+        const int64_t nred = (a.Mp == 1 ? a.M : 1) * gridDim.x;
+        const int64_t blk = (a.Mp == 1 ? m : 0) * gridDim.x + blockIdx.x;
+        const int64_t prow = (int64_t)nl * (P + 2 * D);
+        int* dst = a.partials + (mp * nred + blk) * prow;
+        for (int i = threadIdx.x; i < nl * (P + 2 * D); i += NW * 64) {
+            const int c = i / (P + 2 * D);
+            const int k = i - c * (P + 2 * D);
+            const int* acc = accb + c * ACC;
+            dst[i] = (k >= P) ? ((c & 1) ? acc[A_::o_fold + (k - P)] : 0) : acc[acc_src<H, L, SPARE>(k, U)];
+        }
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[w];
+            a.glp_part[mp * nred + blk] = t * isc;
+        }
     }
 }
 
@@ -1105,35 +1161,51 @@ int flow_train_rev_supported(int D, int S, int L, int U) {
     return rev_lds_bytes(D, S, L, U) <= 160 * 1024 ? 1 : 0;
 }
 
-// workspace: [rimg | g_fold (Mp, 2S, 2, D) + glp_sum (Mp) + gmax (1)]; the tail is zeroed by the backward
+// launch geometry of the backward kernel (shared with the workspace size: the partial rows depend on it)
+static int64_t rev_blocks_x(int64_t M, int64_t N) {
+    const int64_t ntiles = (N + 15) / 16;
+    int64_t bx = (ntiles + kRevNW - 1) / kRevNW;
+    const int64_t cap = (256 + M - 1) / M;
+    return bx > cap ? cap : (bx < 1 ? 1 : bx);
+}
+// workspace: [rimg | g_fold (Mp, 2S, 2, D) + glp_sum (Mp) + gmax (1) + overflow (1) | glp partials | partial rows];
+// g_fold .. overflow are zeroed by the backward
 struct RevWs {
-    int64_t rimg, gfold, total;
+    int64_t rimg, gfold, glpp, part, total, nred;
 };
-static RevWs rev_ws(int64_t Mp, int D, int S, int L) {
+static RevWs rev_ws(int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U) {
     RevWs w;
+    const int H = D / 2;
+    const int64_t P = 2 * (H * U + U) + (int64_t)(L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
+    w.nred = (Mp == 1 ? M : 1) * rev_blocks_x(M, N > 0 ? N : 1);  // workgroups that add into one gradient row
     w.rimg = 0;
     w.gfold = ((Mp * 2 * S * rev_image_floats(D, L) * 4 + 255) / 256) * 256;
-    w.total = w.gfold + ((Mp * 2 * S * 2 * D + Mp + 1) * 4 + 255) / 256 * 256;
+    w.glpp = w.gfold + ((Mp * 2 * S * 2 * D + Mp + 2) * 4 + 255) / 256 * 256;
+    w.part = w.glpp + ((Mp * w.nred * 4 + 255) / 256) * 256;
+    w.total = w.part + ((Mp * w.nred * 2 * S * (P + 2 * D) * 4 + 255) / 256) * 256;
     return w;
 }
-int64_t flow_train_rev_workspace(int64_t Mp, int D, int S, int L) { return rev_ws(Mp, D, S, L).total; }
+int64_t flow_train_rev_workspace(int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U) {
+    return rev_ws(M, Mp, N, D, S, L, U).total;
+}
 
 template <int H, int L>
 static int launch_rev(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
                       const float* g_lp, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int S, int U,
-                      int64_t pstride, int64_t gpstride, char* ws, hipStream_t st) {
+                      int64_t pstride, int64_t gpstride, char* ws, int* overflow_out, hipStream_t st) {
     constexpr int D = 2 * H;
     typedef RevImage<H, L> R;
     static_assert(R::FLOATS % 4 == 0, "image is copied in 16-byte units");
     if (rev_image_floats(D, L) != R::FLOATS) return fail(TNF_ELAUNCH, "flow_bwd_f16: image size mismatch");
     if (rev_lds_bytes(D, S, L, U) != (2 * (int64_t)R::FLOATS + 2 * S * (int64_t)AccLayout<H, L>::INTS + (int64_t)kRevNW * kRevNScr * kScr) * 4)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: LDS size mismatch");
-    const RevWs w = rev_ws(Mp, D, S, L);
+    const RevWs w = rev_ws(M, Mp, N, D, S, L, U);
     float* rimg = reinterpret_cast<float*>(ws + w.rimg);
     float* gfold = reinterpret_cast<float*>(ws + w.gfold);
     float* glp_sum = gfold + Mp * 2 * S * 2 * D;
     unsigned* gmax = reinterpret_cast<unsigned*>(glp_sum + Mp);
-    if (hipMemsetAsync(gfold, 0, (size_t)(Mp * 2 * S * 2 * D + Mp + 1) * sizeof(float), st) != hipSuccess)
+    int* overflow = reinterpret_cast<int*>(gmax + 1);
+    if (hipMemsetAsync(gfold, 0, (size_t)(Mp * 2 * S * 2 * D + Mp + 2) * sizeof(float), st) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: memset failed");
     hipLaunchKernelGGL((flow_rev_images_kernel<H, L>), grid_xm(2 * S, Mp), dim3(64), 0, st, params, bn_mean, bn_alpha,
                        rimg, S, U, pstride, Mp);
@@ -1149,31 +1221,43 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: cannot reserve %zu B of LDS", smem);
     const int64_t ntiles = (N + 15) / 16;
-    int64_t bx = (ntiles + kRevNW - 1) / kRevNW;
-    int64_t cap = (256 + M - 1) / M;
-    if (bx > cap) bx = cap;
+    const int64_t bx = rev_blocks_x(M, N);
     // an accumulator receives iters * NW terms per workgroup; allow 2^13 per term inside the int32 range
     const int64_t adds = ((ntiles + bx * kRevNW - 1) / (bx * kRevNW)) * kRevNW;
     int fbits = 31 - 13;
     for (int64_t v = 1; v < adds; v <<= 1) --fbits;
     if (fbits < 0) fbits = 0;
-    FlowBwdArgs a{z0, g_lp, rimg, gmax, g_z, g_params, gfold, glp_sum, M, Mp, N, gpstride, fl.stage, fl.p_up, S, U,
-                  ldexpf(1.f, fbits)};
+    const float fx = ldexpf(1.f, fbits);
+    FlowBwdArgs a{z0, g_lp, rimg, gmax, g_z, g_params, gfold, glp_sum, M, Mp, N, gpstride, fl.stage, fl.p_up, S, U, fx,
+                  reinterpret_cast<int*>(ws + w.part), reinterpret_cast<float*>(ws + w.glpp), overflow};
     hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(kRevNW * 64), smem, st, a);
     int rc = check_launch("flow_bwd_f16");
     if (rc) return rc;
+    {
+        const int H_ = D / 2;
+        const int P = 2 * (H_ * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H_ + H_);
+        const int64_t prow = (int64_t)2 * S * (P + 2 * D);
+        hipLaunchKernelGGL(flow_bwd_reduce_kernel, dim3((unsigned)((prow + 255) / 256), (unsigned)Mp), dim3(256), 0, st,
+                           reinterpret_cast<const int*>(ws + w.part), reinterpret_cast<const float*>(ws + w.glpp), gmax, overflow,
+                           g_params, gfold, glp_sum, w.nred, 2 * S, P, D, gpstride, fl.stage, fl.p_up, fx);
+        rc = check_launch("flow_bwd_reduce");
+        if (rc) return rc;
+    }
+    if (overflow_out && hipMemcpyAsync(overflow_out, overflow, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(TNF_ELAUNCH, "flow_bwd_f16: copy of the overflow flag failed");
     return launch_flow_fold_backward(params, bn_alpha, gfold, glp_sum, g_params, Mp, D, S, L, U, pstride, gpstride, st);
 }
 
 int launch_flow_bwd_rev(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
                         const float* g_lp, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S,
-                        int L, int U, int64_t pstride, int64_t gpstride, void* ws, hipStream_t st) {
+                        int L, int U, int64_t pstride, int64_t gpstride, void* ws, int* overflow_out, hipStream_t st) {
     if (!flow_train_rev_supported(D, S, L, U))
         return fail(TNF_EUNSUPPORTED, "flow_bwd_f16: D=%d S=%d L=%d U=%d", D, S, L, U);
     if (N <= 0) return TNF_OK;
     char* wsb = reinterpret_cast<char*>(ws);
 #define TNF_REV(HH, LL) \
-    return launch_rev<HH, LL>(z0, params, bn_mean, bn_alpha, g_lp, g_z, g_params, M, Mp, N, S, U, pstride, gpstride, wsb, st)
+    return launch_rev<HH, LL>(z0, params, bn_mean, bn_alpha, g_lp, g_z, g_params, M, Mp, N, S, U, pstride, gpstride, wsb, \
+                              overflow_out, st)
     if (D == 64) {
         if (L == 1) TNF_REV(32, 1);
         if (L == 2) TNF_REV(32, 2);

@@ -171,10 +171,10 @@ int launch_flow_forward_train_bwd(const float* omega, const float* params, const
                                   int U, int64_t pstride, int64_t gpstride, void* ws, hipStream_t st);
 // reversible whole-flow training backward (flow_bwd_f16.hip)
 int flow_train_rev_supported(int D, int S, int L, int U);
-int64_t flow_train_rev_workspace(int64_t Mp, int D, int S, int L);
+int64_t flow_train_rev_workspace(int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U);
 int launch_flow_bwd_rev(const float* z0, const float* params, const float* bn_mean, const float* bn_alpha,
                         const float* g_lp, float* g_z, float* g_params, int64_t M, int64_t Mp, int64_t N, int D, int S,
-                        int L, int U, int64_t pstride, int64_t gpstride, void* ws, hipStream_t st);
+                        int L, int U, int64_t pstride, int64_t gpstride, void* ws, int* overflow_out, hipStream_t st);
 
 int launch_affine(int dtype, const void* z, const void* params, void* z_out, void* log_det,
                   int64_t Mz, int64_t Mp, int64_t N, int D, int inverse, int64_t pstride,

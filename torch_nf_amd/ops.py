@@ -580,7 +580,18 @@ def flow_train_rev_supported(M, Mp, N, D, S, L, U):
 
 class _FlowLogProbRevFn(torch.autograd.Function):
     """log_prob through the whole-flow kernel (tnf_flow_log_prob_fwd_rev_f32); the backward rebuilds every
-    layer's input from z0 inside one kernel (tnf_flow_log_prob_bwd_rev_f32), so no activations are kept."""
+    layer's input from z0 inside one kernel (tnf_flow_log_prob_bwd_rev_f32), so no activations are kept.
+
+    The backward's gradient accumulators are 32-bit fixed point and its cross-workgroup sum runs in block order (what
+    makes the parameter gradient reproducible bit for bit).  A gradient term beyond their budget -- a heavy-tailed
+    sample, whose deltas also approach the f16 range of the split operands -- is flagged by the kernel (its own result
+    is NaN then, never a wrapped sum), and the step is recomputed through the per-layer pair with fp32 layer kernels
+    (tnf_flow_log_prob_fwd_f32 / _bwd_f32, no such budget).  Reading the flag costs one host round trip per backward;
+    `check_overflow = False` (or a HIP-graph capture, where the flag cannot be read) skips it: such a step then
+    yields a NaN gradient instead of the fallback's."""
+
+    check_overflow = True
+    overflow_fallbacks = 0  # how often the fp32 pair had to take over (diagnostic)
 
     @staticmethod
     def forward(ctx, z, params, bn_mean, bn_alpha, D, S, L, U):
@@ -595,13 +606,13 @@ class _FlowLogProbRevFn(torch.autograd.Function):
         check(lib.tnf_flow_log_prob_fwd_rev_f32(zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
                                                 lp.data_ptr(), z0.data_ptr(), M, Mp, N, D, S, L, U, pstride,
                                                 _lib.stream_ptr()))
-        ctx.save_for_backward(z0, pc, mean_c, alpha_c)
+        ctx.save_for_backward(z0, pc, mean_c, alpha_c, zc)  # zc: the caller's tensor (no copy), for the fallback only
         ctx.cfg = (D, S, L, U, pstride, z.device, params.device, tuple(params.shape))
         return lp if z.device == dev else lp.to(z.device)
 
     @staticmethod
     def backward(ctx, g_lp):
-        z0, pc, mean_c, alpha_c = ctx.saved_tensors
+        z0, pc, mean_c, alpha_c, zc = ctx.saved_tensors
         D, S, L, U, pstride, z_home, p_home, p_shape = ctx.cfg
         dev = z0.device
         M, N = z0.shape[0], z0.shape[1]
@@ -609,15 +620,47 @@ class _FlowLogProbRevFn(torch.autograd.Function):
         g = _stage(g_lp.float(), dev)
         gz = torch.empty_like(z0) if ctx.needs_input_grad[0] else None
         gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
-        ws_bytes = check(lib.tnf_flow_train_rev_workspace_bytes(Mp, D, S, L, U))
+        ws_bytes = check(lib.tnf_flow_train_rev_workspace_bytes(M, Mp, N, D, S, L, U))
         ws = _workspace(ws_bytes, dev)
+        look = _FlowLogProbRevFn.check_overflow and not torch.cuda.is_current_stream_capturing()
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if look else None
         check(lib.tnf_flow_log_prob_bwd_rev_f32(z0.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
                                                 g.data_ptr(), gz.data_ptr() if gz is not None else None,
                                                 gp.data_ptr(), M, Mp, N, D, S, L, U, pstride, gp.shape[1],
-                                                ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+                                                ws.data_ptr(), ws.numel(), None if flag is None else flag.data_ptr(),
+                                                _lib.stream_ptr()))
+        if flag is not None and int(flag.item()) != 0 and flow_train_supported(M, Mp, N, D, S, L, U):
+            # a term left the fixed-point budget: the same step through the per-layer pair, fp32 layer kernels
+            _FlowLogProbRevFn.overflow_fallbacks += 1
+            gz, gp = _flow_log_prob_grad_fp32(zc, pc, pstride, mean_c, alpha_c, g, D, S, L, U, p_shape,
+                                              ctx.needs_input_grad[0])
         if gz is not None and z_home != dev:
             gz = gz.to(z_home)
         return gz, (gp if p_home == dev else gp.to(p_home)), None, None, None, None, None, None
+
+
+def _flow_log_prob_grad_fp32(zc, pc, pstride, mean_c, alpha_c, g, D, S, L, U, p_shape, want_gz):
+    """Gradient of log_prob w.r.t. (z, params) through the per-layer training pair with the fp32-MFMA layer backward."""
+    dev = zc.device
+    M, N = zc.shape[0], zc.shape[1]
+    Mp = pc.shape[0]
+    lp = torch.empty((M, N), dtype=torch.float32, device=dev)
+    states = torch.empty((2 * S - 1, M, N, D), dtype=torch.float32, device=dev)
+    ws_bytes = check(lib.tnf_flow_train_workspace_bytes(M, Mp, N, D, S, L, U))
+    ws = _workspace(ws_bytes, dev)
+    check(lib.tnf_flow_log_prob_fwd_f32(zc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(), lp.data_ptr(),
+                                        states.data_ptr(), M, Mp, N, D, S, L, U, pstride, ws.data_ptr(), ws.numel(),
+                                        _lib.stream_ptr()))
+    gz = torch.empty_like(zc)
+    gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+    check(lib.tnf_set_option(_lib.OPT_TRAIN_BWD_FP32, 1))
+    try:
+        check(lib.tnf_flow_log_prob_bwd_f32(zc.data_ptr(), states.data_ptr(), pc.data_ptr(), mean_c.data_ptr(),
+                                            alpha_c.data_ptr(), g.data_ptr(), gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, S,
+                                            L, U, pstride, gp.shape[1], ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    finally:
+        check(lib.tnf_set_option(_lib.OPT_TRAIN_BWD_FP32, 0))
+    return (gz if want_gz else None), gp
 
 
 def flow_log_prob_train(z, params, bn_mean, bn_alpha, D, S, L, U, reversible=True):
