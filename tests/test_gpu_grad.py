@@ -440,3 +440,55 @@ def test_flow_reversible_backward_overflow_falls_back(tnf, oracle):
                                                    gp.shape[1], ws.data_ptr(), nbytes, flag.data_ptr(), L_.stream_ptr()))
         assert int(flag.item()) == want_flag
         assert bool(torch.isnan(gp).any()) == bool(want_flag), (want_flag, int(torch.isnan(gp).sum()), gp.numel())
+
+
+@pytest.mark.parametrize("arch,D,S", [("coupling", 64, 2), ("coupling", 6, 1), ("AR", 6, 1)])
+def test_bn_statistics_stay_in_graph(tnf, oracle, arch, D, S):
+    """The reference caches last_mean / last_alpha WITHOUT detach (bijectors.py:414-415): `nf(N)` followed by
+    `nf.log_prob(z)` (or the inverse) in one graph back-propagates through the batch moments of the sampling call.
+    The per-bijector path (nf.fused_batch_forward = False) keeps that behaviour; log_prob notices statistics that are
+    still in a graph and differentiates through them.  Gradient of a loss on both calls vs torch autograd over the
+    oracle (whose batch-mode BatchNorm is the reference's literal expression) -- and it differs measurably from the
+    gradient with detached statistics, so the test is not vacuous."""
+    L, U, M, N = 2, 15, 2, 96
+    rng = np.random.RandomState(D + S)
+    np.random.seed(3)
+    nf = tnf.NormFlow(D, True, arch, S, L, U)
+    nf.fused_batch_forward = False  # the reference's per-bijector composition
+    p0 = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float()
+    omega = rng.normal(0, 1, (M, N, D))
+    z_eval = torch.tensor(rng.normal(0, 1, (M, 7, D))).float()
+
+    def oracle_loss(detach):
+        p = p0.clone().requires_grad_()
+        if arch == "coupling":
+            z, lq, st = oracle.flow_forward(omega, p, D, S, L, U, None)
+            if detach:
+                st = [(m.detach(), a.detach()) for m, a in st]
+            lp = oracle.flow_log_prob(z_eval, p, D, S, L, U, st)
+        else:
+            Ms = [Mk[0].numpy() for Mk in nf.bijectors[0].Ms]
+            z, lq, st = oracle.ar_flow_forward(omega, p, D, L, U, Ms, None)
+            if detach:
+                st = (st[0].detach(), st[1].detach())
+            lp = oracle.ar_flow_log_prob(z_eval, p, D, L, U, Ms, st)
+        loss = lq.mean() + 0.5 * lp.double().mean() + 0.1 * (z.double() ** 2).mean()
+        loss.backward()
+        return float(loss.detach()), p.grad
+
+    loss_ref, g_ref = oracle_loss(False)
+    _, g_det = oracle_loss(True)
+    p = p0.cuda().requires_grad_()
+    z, lq = nf._forward_from(omega, p, freeze_bn=False)
+    assert all(b.get_last_alpha().requires_grad for b in nf._bn_layers())
+    lp = nf.log_prob(z_eval.cuda(), p)
+    loss = lq.mean() + 0.5 * lp.double().mean() + 0.1 * (z.double() ** 2).mean()
+    loss.backward()
+    scale = float(g_ref.abs().max())
+    assert abs(float(loss.detach()) - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
+    assert float((g_det - g_ref).abs().max()) > 1e-3 * scale, "detached statistics must give a different gradient"
+    torch.testing.assert_close(p.grad.cpu() / scale, g_ref / scale, rtol=5e-3, atol=2e-5)
+    # installed statistics (set_last_stats) are constants again: the fused paths come back
+    for b in nf._bn_layers():
+        b.set_last_stats(b.get_last_mean(), b.get_last_alpha())
+    assert not nf._stats_in_graph()

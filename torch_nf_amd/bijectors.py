@@ -180,7 +180,9 @@ class BatchNorm(Bijector):
     of its last batch-mode forward (bijectors.py:321-426).
 
     forward(use_last=False): statistics over all M*N rows (HIP reduction in float64),
-        z_norm = (z - mu)/sqrt(var + eps); caches mean and alpha.
+        z_norm = (z - mu)/sqrt(var + eps); caches mean and alpha -- WITH their graph when autograd is
+        recording, like the reference (bijectors.py:414-415: no detach), so that `nf(N)` followed by
+        `nf.log_prob(z)` or the inverse in one graph back-propagates through the batch moments.
     forward(use_last=True):  (z - last_mean)/last_alpha.
     inverse:                 z*last_alpha + last_mean.
     log_det = -sum(log(alpha)) (0-dim) in every case.

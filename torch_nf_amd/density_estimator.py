@@ -180,7 +180,7 @@ class NormFlow(DensityEstimator):
         """[MAF, BatchNorm, Affine] as one kernel: float32, no autograd, shape covered by the MFMA MAF kernel."""
         if self.arch_type != "AR" or z.dtype != torch.float32 or params.dtype != torch.float32:
             return False
-        if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad):
+        if torch.is_grad_enabled() and (z.requires_grad or params.requires_grad or self._stats_in_graph()):
             return False
         return z.dim() == 3 and ops.ar_flow_supported(self.D, self.num_layers, self.num_units)
 
@@ -207,9 +207,16 @@ class NormFlow(DensityEstimator):
                 and ops.flow_train_supported(z.size(0), params.size(0), 32, self.D, self.num_stages, self.num_layers,
                                              self.num_units))
 
+    def _stats_in_graph(self):
+        """Do the cached BatchNorm statistics still carry the graph of the batch-mode forward that produced them
+        (per-bijector forward under autograd -- the reference's behaviour, bijectors.py:414-415)?  Then every later
+        use of them in the same graph must differentiate through them: only the per-bijector composition does."""
+        return torch.is_grad_enabled() and any(b.get_last_mean().requires_grad or b.get_last_alpha().requires_grad
+                                               for b in self._bn_layers())
+
     def _fused_ok(self, z, params):
         """One-call fused path: coupling stack, float32, no autograd, MFMA-covered shape."""
-        if self.arch_type != "coupling":
+        if self.arch_type != "coupling" or self._stats_in_graph():
             return False
         if z.dtype != torch.float32 or params.dtype != torch.float32:
             return False
@@ -390,6 +397,8 @@ class NormFlow(DensityEstimator):
         return self._core_log_prob(z, params)
 
     def _train_path(self, z, params):
+        if self._stats_in_graph():
+            return None  # the fused training pairs treat the statistics as constants
         shape = (z.size(0), params.size(0), z.size(1), self.D, self.num_stages, self.num_layers, self.num_units)
         if getattr(self, "reversible_training", True) and ops.flow_train_rev_supported(*shape):
             return "reversible"
@@ -400,6 +409,7 @@ class NormFlow(DensityEstimator):
     def _ar_train_ok(self, z, params):
         """Training through the AR stack with z a constant: one forward kernel, one backward kernel."""
         return (self.arch_type == "AR" and getattr(self, "fused_ar_training", True) and torch.is_grad_enabled()
+                and not self._stats_in_graph()
                 and params.requires_grad and not z.requires_grad and z.dim() == 3
                 and z.dtype == torch.float32 and params.dtype == torch.float32
                 and z.size(0) == max(z.size(0), params.size(0))

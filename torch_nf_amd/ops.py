@@ -183,47 +183,83 @@ def bn_apply_raw(z, mean, alpha, inverse):
 
 
 class _BnApplyFn(torch.autograd.Function):
-    """Cached-statistics BatchNorm; gradients flow to z only (the cached statistics are
-    treated as constants here -- see DESIGN.md, 'BatchNorm and autograd')."""
+    """Cached-statistics BatchNorm.  Gradients flow to z and -- when the cached statistics still carry the graph of the
+    batch-mode forward that produced them, as the reference's do (bijectors.py:414-415, no detach) -- to mean and alpha:
+      inverse  out = z alpha + mean        g_alpha = sum g_out z      - g_ld / alpha,  g_mean = sum g_out
+      forward  out = (z - mean) / alpha    g_alpha = -sum g_out out / alpha - g_ld / alpha,  g_mean = -sum g_out / alpha
+    (log_det = -sum log alpha in both).  The per-feature sums are a handful of torch reductions on the device."""
 
     @staticmethod
     def forward(ctx, z, mean, alpha, inverse):
         z_out, log_det = bn_apply_raw(z, mean, alpha, inverse)
-        ctx.save_for_backward(alpha)
+        stats_grad = mean.requires_grad or alpha.requires_grad
+        ctx.save_for_backward(alpha, *((z if inverse else z_out,) if stats_grad else ()))
         ctx.inverse = inverse
+        ctx.stats_grad = stats_grad
         return z_out, log_det
 
     @staticmethod
     def backward(ctx, g_z, g_ld):
         from . import grad
 
-        (alpha,) = ctx.saved_tensors
-        return grad.bn_apply_backward(g_z, alpha, ctx.inverse), None, None, None
+        alpha = ctx.saved_tensors[0]
+        gz = grad.bn_apply_backward(g_z, alpha, ctx.inverse) if ctx.needs_input_grad[0] else None
+        g_mean = g_alpha = None
+        if ctx.stats_grad:
+            v = ctx.saved_tensors[1]
+            dev = v.device
+            a = alpha.detach().to(dev).to(v.dtype)
+            D = v.shape[-1]
+            g_alpha = torch.zeros(D, dtype=v.dtype, device=dev)
+            g_mean = torch.zeros(D, dtype=v.dtype, device=dev)
+            if g_z is not None:
+                go = g_z.to(dev).reshape(-1, D)
+                if ctx.inverse:
+                    g_alpha = (go * v.reshape(-1, D)).sum(0)
+                    g_mean = go.sum(0)
+                else:
+                    g_alpha = -(go * v.reshape(-1, D)).sum(0) / a
+                    g_mean = -go.sum(0) / a
+            if g_ld is not None:
+                g_alpha = g_alpha - g_ld.to(dev).to(v.dtype) / a
+            g_alpha, g_mean = g_alpha.to(alpha.dtype).to(alpha.device), g_mean.to(alpha.dtype).to(alpha.device)
+        return gz, g_mean, g_alpha, None
 
 
 def bn_apply(z, mean, alpha, inverse):
-    if torch.is_grad_enabled() and z.requires_grad:
+    if torch.is_grad_enabled() and (z.requires_grad or mean.requires_grad or alpha.requires_grad):
         return _BnApplyFn.apply(z, mean, alpha, inverse)
     return bn_apply_raw(z, mean, alpha, inverse)
 
 
 class _BnBatchFn(torch.autograd.Function):
-    """Batch-statistics BatchNorm with gradients to z (through the normalisation, the batch
-    moments and the log-det).  mean / alpha are returned as constants."""
+    """Batch-statistics BatchNorm with gradients to z through the normalisation, the batch moments and the log-det --
+    and through the RETURNED statistics: mean and alpha are differentiable outputs, so a later use of the cached
+    statistics in the same graph (nf(N) then nf.log_prob(z), the reference's pattern: bijectors.py:414-415 caches them
+    without detach) back-propagates into this batch:  mean = sum z / R,  alpha = sqrt(var_b + eps)  give
+    g_z += g_mean / R + g_alpha z_norm / R  (z_norm = (z - mean) / alpha)."""
 
     @staticmethod
     def forward(ctx, z, eps):
         z_norm, log_det, mean, alpha = _bn_batch_forward_raw(z, eps)
         ctx.save_for_backward(z_norm, alpha)
-        ctx.mark_non_differentiable(mean, alpha)
         return z_norm, log_det, mean, alpha
 
     @staticmethod
-    def backward(ctx, g_zn, g_ld, _g_mean, _g_alpha):
+    def backward(ctx, g_zn, g_ld, g_mean, g_alpha):
         from . import grad
 
         z_norm, alpha = ctx.saved_tensors
-        return grad.bn_batch_backward(z_norm, alpha, g_zn, g_ld), None
+        gz = grad.bn_batch_backward(z_norm, alpha, g_zn, g_ld)
+        if g_mean is not None or g_alpha is not None:
+            rows = z_norm.numel() // z_norm.shape[-1]
+            extra = 0.0
+            if g_mean is not None:
+                extra = g_mean.to(gz.device).to(gz.dtype) / rows
+            if g_alpha is not None:
+                extra = extra + z_norm.to(gz.device) * (g_alpha.to(gz.device).to(gz.dtype) / rows)
+            gz = gz + extra
+        return gz, None
 
 
 def bn_batch_forward(z, eps):
