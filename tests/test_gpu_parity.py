@@ -754,3 +754,39 @@ def test_operand_range(tnf, oracle, D):
         zerr = ((z0.cpu().double() - z0_want).abs() / scale).max().item()
         zbar = max(2e-5, 4.0 * ((z0_f32.double() - z0_want).abs() / scale).max().item())
         assert zerr <= zbar, "%s: z0 err %.3g > %.3g" % (name, zerr, zbar)
+
+
+def test_bf16_operand_experiment_is_scoped_and_close(tnf):
+    """TNF_OPT_OPERAND_PREC (the fp32-vs-bf16 sweep of BASELINE configs[4], tools/bf16_sweep.py): inside
+    ops.operand_precision("bf16") the coupling and autoregressive log_prob kernels use bf16 conditioner operands
+    -- results move, but stay within bf16's 2^-8 operand rounding of the fp32 path -- and the default path is
+    bit-identical before and after the block.  Parity unpinned: the reference has no reduced-precision mode."""
+    ops, L_ = tnf.ops, tnf._lib
+    D, S, L, U, N = 64, 4, 2, 15, 4096
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=5)
+    _install_stats(nf, [m.numpy() for m, _ in stats], [a.numpy() for _, a in stats])
+    mean, alpha = nf._bn_stats(torch.device("cuda"))
+    z = torch.randn(1, N, D, generator=torch.Generator().manual_seed(6)).cuda()
+    pc = params.cuda()
+    for fusion in (L_.FUSE_FLOW, L_.FUSE_LAYER):
+        ref = ops.flow_log_prob_raw(z, pc, mean, alpha, D, S, L, U, fusion)[0]
+        with ops.operand_precision("bf16"):
+            low = ops.flow_log_prob_raw(z, pc, mean, alpha, D, S, L, U, fusion)[0]
+        again = ops.flow_log_prob_raw(z, pc, mean, alpha, D, S, L, U, fusion)[0]
+        assert torch.equal(ref, again)
+        err = _rel_err(low.cpu(), ref.cpu().double())
+        assert 1e-6 < err < 3e-2, err
+    # autoregressive flow (the LFI step's kernels)
+    D, L, U = 6, 2, 12
+    torch.manual_seed(8)
+    np.random.seed(8)
+    nf = tnf.NormFlow(D, False, "AR", 1, L, U)
+    with torch.no_grad():
+        nf(256)
+        za = torch.randn(1, 2048, D).cuda()
+        ref = nf.log_prob(za)
+        with ops.operand_precision("bf16"):
+            low = nf.log_prob(za)
+        assert torch.equal(ref, nf.log_prob(za))
+    err = _rel_err(low.cpu(), ref.cpu().double())
+    assert 1e-6 < err < 3e-2, err

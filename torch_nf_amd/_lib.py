@@ -17,6 +17,7 @@ F32, F64 = 0, 1
 LD_STORE, LD_ADD, LD_SUB = 0, 1, -1
 FUSE_AUTO, FUSE_LAYER, FUSE_FLOW = 0, 1, 2
 OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT, OPT_COND_VARIANT, OPT_TRAIN_BWD_FP32 = 1, 2, 3, 4, 5
+OPT_OPERAND_PREC = 6
 EUNSUPPORTED = -2
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float

@@ -7,6 +7,7 @@
 namespace tnf {
 
 thread_local int g_force_generic = 0;
+thread_local int g_operand_prec = 0;
 
 char* err_buf() {
     static thread_local char buf[512] = {0};
@@ -71,6 +72,11 @@ const char* tnf_last_error(void) { return err_buf(); }
 int tnf_set_option(int32_t key, int32_t value) {
     if (key == TNF_OPT_FORCE_GENERIC) {
         g_force_generic = value;
+        return TNF_OK;
+    }
+    if (key == TNF_OPT_OPERAND_PREC) {
+        if (value != 0 && value != 1) return fail(TNF_EINVAL, "tnf_set_option: operand precision %d", value);
+        g_operand_prec = value;
         return TNF_OK;
     }
     if (key == TNF_OPT_FLOW_VARIANT) {
@@ -320,6 +326,7 @@ static int ar_flow_run(const char* fn, int inverse, const float* z, const float*
     a.ld_out = sum_log_det; a.ld_sign = 1.f; a.ldc = ldc; a.add_ldc = 1; a.log_prob = log_prob;
     a.iv = interval_consts;
     a.Mz = M_z; a.Mp = M_p; a.N = N; a.D = D; a.L = L; a.U = U; a.inverse = inverse;
+    a.bf16 = g_operand_prec == 1;
     return launch_maf_mfma(a, as_stream(stream));
 }
 
@@ -644,6 +651,16 @@ static int flow_log_prob_impl(const float* z, const float* params, const float* 
     const bool narrow = mfma_supported(D, L, U);
     const int64_t img_floats = narrow ? mfma_image_floats(D, L) : wide_image_floats(D, L, U);
     const bool f16 = use_fused && g_flow_variant >= 10;  // builds its own (split-f16) images
+    if (g_operand_prec == 1) {
+        // the bf16 experiment runs on the layer-range kernel: all 2S layers in one launch, or one layer per launch
+        if (!narrow || !flow_range2_supported(D, L, U, use_fused ? 2 * S : 1))
+            return fail(TNF_EUNSUPPORTED, "tnf_flow_log_prob_f32: no bf16-operand kernel for D=%d S=%d L=%d U=%d", D, S, L, U);
+        float* zb = z0 ? z0 : reinterpret_cast<float*>(wsb + w.zbuf);
+        float* lb = sum_log_det ? sum_log_det : reinterpret_cast<float*>(wsb + w.ldbuf);
+        return launch_flow_chain2(z, use_fused ? nullptr : zb, use_fused ? nullptr : lb, z0, sum_log_det, log_prob, M_z, M_p, N, D,
+                                  S, L, U, params, pstride, bn_mean, bn_alpha, interval_consts, nullptr,
+                                  use_fused ? 2 * S : 1, st, 1);
+    }
     const bool chain2 = !use_fused && narrow && g_layer_variant >= 10 && flow_range2_supported(D, L, U, 1);
     if (interval_consts && !f16 && !chain2)
         return fail(TNF_EUNSUPPORTED, "tnf_flow_log_prob_f32: a fused support layer needs the whole-flow kernel");
@@ -914,6 +931,12 @@ int tnf_flow_log_prob_fwd_rev_f32(const float* z, const float* params, const flo
     if (!z || !params || !bn_mean || !bn_alpha || !log_prob || !z0)
         return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_rev_f32: NULL pointer");
     if (!aligned16(z) || !aligned16(z0)) return fail(TNF_EINVAL, "tnf_flow_log_prob_fwd_rev_f32: z / z0 must be 16-byte aligned");
+    if (g_operand_prec == 1) {  // the bf16 experiment: forward activations from bf16 operands (the backward stays split-f16)
+        if (!flow_range2_supported(D, L, U, 2 * S))
+            return fail(TNF_EUNSUPPORTED, "tnf_flow_log_prob_fwd_rev_f32: no bf16-operand kernel for D=%d S=%d L=%d U=%d", D, S, L, U);
+        return launch_flow_chain2(z, nullptr, nullptr, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, params, pstride, bn_mean,
+                                  bn_alpha, nullptr, nullptr, 2 * S, as_stream(stream), 1);
+    }
     if (g_flow_variant == 10 && flow_fused2_supported(D, S, L, U))
         return launch_flow_fused2(z, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha, nullptr,
                                   nullptr, as_stream(stream));

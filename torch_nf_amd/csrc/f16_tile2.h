@@ -55,6 +55,22 @@ __device__ __forceinline__ HiLo split2r(float v0, float v1) {
     return HiLo{hb, lb};
 }
 
+// ---- reduced-precision experiment (BASELINE configs[4], "fp32 vs bf16 tolerance sweep"): PREC = 1 evaluates every
+// contraction as ONE bf16 MFMA (operands rounded to bf16 once, fp32 accumulate) instead of the three split-f16
+// products.  Not a parity path: tools/bf16_sweep.py measures what it costs in accuracy and buys in time.
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));  // v_cvt_pk_bf16_f32
+}
+__device__ __forceinline__ f4 mfma16b(u2 a, u2 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f4 mfma32b(u4 a, u4 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
 // four values -> hi(4), lo(4)
 __device__ __forceinline__ void split4r(f4 v, h4& hi, h4& lo) {
     const HiLo a = split2r(v[0], v[1]), b = split2r(v[2], v[3]);
@@ -141,10 +157,15 @@ __device__ __forceinline__ int layer_kappa(const float* __restrict__ p, int U, i
     return norm_exponent(wave_max(mx), -30, 30);
 }
 
-// K = 16 weight group: four fp32 values -> [hi(4) | lo(4)]
+// K = 16 weight group: four fp32 values -> [hi(4) | lo(4)]  (PREC = 1: [bf16(4) | 0])
+template <int PREC>
 __device__ __forceinline__ void store_k16(u4* gd, const float (&v)[4]) {
-    const HiLo a = split2r(v[0], v[1]), b = split2r(v[2], v[3]);
-    *gd = u4{a.hi, b.hi, a.lo, b.lo};
+    if constexpr (PREC == 1) {
+        *gd = u4{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), 0u, 0u};
+    } else {
+        const HiLo a = split2r(v[0], v[1]), b = split2r(v[2], v[3]);
+        *gd = u4{a.hi, b.hi, a.lo, b.lo};
+    }
 }
 
 // One wave builds the image of the coupling layer c (walk position k = 2S-1-c of the inverse pass).
@@ -153,7 +174,7 @@ __device__ __forceinline__ void store_k16(u4* gd, const float (&v)[4]) {
 //   sc_in    2^kappa_k: the conditioner registers hold (true value before foldc) / sc_in
 //   sc_prev  2^kappa_{k-1} (ignored when foldprev == NULL)
 //   sig_next 2^-kappa_{k+1}: factor the transformed half is emitted with (1 for the last layer walked)
-template <int H, int L>
+template <int H, int L, int PREC = 0>
 __device__ __forceinline__ void build_image2(float* img, const float* __restrict__ p, int U, int lane, const float* foldc,
                                              const float* foldprev, int c, float sc_in, float sc_prev, float sig_next) {
     typedef Img2<H, L> I;
@@ -234,25 +255,30 @@ __device__ __forceinline__ void build_image2(float* img, const float* __restrict
             u4 hi, lo;
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) {
-                const HiLo s = split2r(w.w0[net][2 * pp], w.w0[net][2 * pp + 1]);
-                hi[pp] = s.hi;
-                lo[pp] = s.lo;
+                if constexpr (PREC == 1) {
+                    hi[pp] = pk_bf16(w.w0[net][2 * pp], w.w0[net][2 * pp + 1]);
+                    lo[pp] = 0u;
+                } else {
+                    const HiLo s = split2r(w.w0[net][2 * pp], w.w0[net][2 * pp + 1]);
+                    hi[pp] = s.hi;
+                    lo[pp] = s.lo;
+                }
             }
             g0[(2 * net) * 64] = hi;
             g0[(2 * net + 1) * 64] = lo;
         } else {
             const float v[4] = {w.w0[net][0], w.w0[net][1], w.w0[net][2], w.w0[net][3]};
-            store_k16(gd + I::k_l0(net) * 64, v);
+            store_k16<PREC>(gd + I::k_l0(net) * 64, v);
         }
 #pragma unroll
         for (int l = 0; l < L - 1; ++l) {
             const float v[4] = {w.wh[l][net][0], w.wh[l][net][1], w.wh[l][net][2], w.wh[l][net][3]};
-            store_k16(gd + I::k_h(l, net) * 64, v);
+            store_k16<PREC>(gd + I::k_h(l, net) * 64, v);
         }
 #pragma unroll
         for (int mo = 0; mo < HT; ++mo) {
             const float v[4] = {w.w2[net][mo][0], w.w2[net][mo][1], w.w2[net][mo][2], w.w2[net][mo][3]};
-            store_k16(gd + I::k_o(net, mo) * 64, v);
+            store_k16<PREC>(gd + I::k_o(net, mo) * 64, v);
         }
     }
     if ((lane & 15) == 0) {
@@ -279,9 +305,78 @@ __device__ __forceinline__ void build_image2(float* img, const float* __restrict
 
 // One coupling layer (inverse direction) on NT tiles.  x: conditioner registers (unchanged), y: transformed half,
 // ssum2[t] += this lane's share of sum(s) log2(e).  SLOW: layer 0 in exact fp32 MFMAs (out-of-range inputs).
-template <int H, int L, int NT, bool SLOW>
+// the bf16 experiment: same image layout (the bf16 weights sit in the hi slots), one MFMA per contraction
+template <int H, int L, int NT>
+__device__ __forceinline__ void coupling_tile2_bf16(const float* img, int lane, const f4 (&x)[NT][H / 16], f4 (&y)[NT][H / 16],
+                                                    float (&ssum2)[NT]) {
+    typedef Img2<H, L> I;
+    constexpr int HT = I::HT;
+    const u4* g0 = reinterpret_cast<const u4*>(img) + lane;
+    const u4* gd = reinterpret_cast<const u4*>(img + I::OFF_D) + lane;
+    const float* bl = img + I::OFF_B + (lane >> 4) * 4;
+    auto bias = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(bl + g * 16); };
+    auto w16 = [&](int g) -> u2 { const u4 v = gd[g * 64]; return u2{v[0], v[1]}; };
+    const f4 Sa = *reinterpret_cast<const f4*>(img + I::OFF_S);
+    f4 Sb = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (L == 3) Sb = *reinterpret_cast<const f4*>(img + I::OFF_S + 4);
+    auto Sc = [&](int stage, int net) -> float { return (2 * stage + net) < 4 ? Sa[2 * stage + net] : Sb[2 * stage + net - 4]; };
+    auto b4 = [&](f4 v) -> u2 { return u2{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])}; };
+
+    f4 acc[NT][2];
+    if constexpr (H == 32) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const u2 a = b4(x[t][0]), b = b4(x[t][1]);
+            const u4 xb = u4{a[0], a[1], b[0], b[1]};
+#pragma unroll
+            for (int net = 0; net < 2; ++net) acc[t][net] = mfma32b(g0[(2 * net) * 64], xb, bias(I::b_b0(net)));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const u2 xb = b4(x[t][0]);
+#pragma unroll
+            for (int net = 0; net < 2; ++net) acc[t][net] = mfma16b(w16(I::k_l0(net)), xb, bias(I::b_b0(net)));
+        }
+    }
+    u2 rb[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int net = 0; net < 2; ++net) rb[t][net] = b4(sig2s_4(acc[t][net], Sc(0, net)));
+#pragma unroll
+    for (int l = 0; l < L - 1; ++l) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+                acc[t][net] = mfma16b(w16(I::k_h(l, net)), rb[t][net], bias(I::b_bh(l, net)));
+                rb[t][net] = b4(sig2s_4(acc[t][net], Sc(l + 1, net)));
+            }
+    }
+#pragma unroll
+    for (int mo = 0; mo < HT; ++mo) {
+        const f4 ay = *reinterpret_cast<const f4*>(img + I::OFF_A + 16 * mo + 4 * (lane >> 4));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 tt = mfma16b(w16(I::k_o(0, mo)), rb[t][0], bias(I::b_b2(0, mo)));
+            const f4 sv = mfma16b(w16(I::k_o(1, mo)), rb[t][1], bias(I::b_b2(1, mo)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ssum2[t] += sv[j];
+                y[t][mo][j] = __builtin_fmaf(y[t][mo][j], ay[j], -tt[j]) * __builtin_amdgcn_exp2f(-sv[j]);
+            }
+        }
+    }
+}
+
+template <int H, int L, int NT, bool SLOW, int PREC = 0>
 __device__ __forceinline__ void coupling_tile2(const float* img, int lane, const f4 (&x)[NT][H / 16], f4 (&y)[NT][H / 16],
                                                float (&ssum2)[NT]) {
+    if constexpr (PREC == 1) {
+        coupling_tile2_bf16<H, L, NT>(img, lane, x, y, ssum2);
+        return;
+    }
     typedef Img2<H, L> I;
     constexpr int HT = I::HT;
     const u4* g0 = reinterpret_cast<const u4*>(img) + lane;

@@ -336,7 +336,7 @@ __device__ __forceinline__ void fold_inverse(const Flow2Args& a, const float* pr
 
 // HI_FIRST / HI_LAST: layer c_hi / c_lo conditions on the upper half (c odd).  Compile-time, so that the two register
 // halves are never selected by a run-time index (that would put them in scratch memory).
-template <int H, int L, int NT, int NWAVES, bool HI_FIRST, bool HI_LAST>
+template <int H, int L, int NT, int NWAVES, bool HI_FIRST, bool HI_LAST, int PREC>
 __global__ void __launch_bounds__(NWAVES * 64)
 flow_range2_kernel(Range2Args ra) {
     constexpr int D = 2 * H;
@@ -401,8 +401,8 @@ flow_range2_kernel(Range2Args ra) {
         const float* foldprev = c < nl - 1 ? fold + (c + 1 - c_lo) * 2 * D : nullptr;
         const float sc_prev = c < c_hi ? pow2i(kap[c + 1 - c_lo]) : 1.f;
         const float sig_next = c > c_lo ? pow2i(-kap[c - 1 - c_lo]) : 1.f;
-        build_image2<H, L>(img + (c - c_lo) * I::FLOATS, prow + (c >> 1) * a.stage_stride + (c & 1) * a.low_off, a.U, lane,
-                           fold + (c - c_lo) * 2 * D, foldprev, c, sc_in, sc_prev, sig_next);
+        build_image2<H, L, PREC>(img + (c - c_lo) * I::FLOATS, prow + (c >> 1) * a.stage_stride + (c & 1) * a.low_off, a.U,
+                                 lane, fold + (c - c_lo) * 2 * D, foldprev, c, sc_in, sc_prev, sig_next);
     }
     {   // conditioner half of the range's last layer: true value = fin_A * register + fin_B; register * 2^kappa = what it
         // was before that layer's fold
@@ -533,8 +533,8 @@ flow_range2_kernel(Range2Args ra) {
     auto layers = [&](auto slow, f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssum)[NT]) {
         for (int c = c_hi; c >= c_lo; --c) {
             const float* im = img + (c - c_lo) * I::FLOATS;
-            if (c & 1) coupling_tile2<H, L, NT, decltype(slow)::value>(im, lane, dhi, dlo, ssum);
-            else coupling_tile2<H, L, NT, decltype(slow)::value>(im, lane, dlo, dhi, ssum);
+            if (c & 1) coupling_tile2<H, L, NT, decltype(slow)::value, PREC>(im, lane, dhi, dlo, ssum);
+            else coupling_tile2<H, L, NT, decltype(slow)::value, PREC>(im, lane, dlo, dhi, ssum);
         }
     };
 
@@ -564,7 +564,7 @@ flow_range2_kernel(Range2Args ra) {
         float chk = ssum[0];
 #pragma unroll
         for (int t = 1; t < NT; ++t) chk += ssum[t];
-        if (__builtin_expect(__any(chk != chk), 0)) {  // out-of-range input: exact first-layer contractions (f16_tile2.h)
+        if (PREC == 0 && __builtin_expect(__any(chk != chk), 0)) {  // out-of-range input: exact first-layer contractions
             {
                 f4 again[NI];  // (the prefetch of the next group stays in `raw`)
                 load_raw(grp, again, ldp);
@@ -717,13 +717,13 @@ int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log
 }
 
 
-template <int H, int L>
+template <int H, int L, int PREC>
 static int launch_range_t(const Range2Args& ra, int64_t M, hipStream_t st) {
     constexpr int NT = TNF2_RANGE_NT, NW = TNF2_RANGE_NW;
     const size_t smem = (size_t)range2_lds_floats<H, L>(ra.c_hi - ra.c_lo + 1) * sizeof(float);
     const bool hf = (ra.c_hi & 1) != 0, hl = (ra.c_lo & 1) != 0;
-    auto kern = hf ? (hl ? flow_range2_kernel<H, L, NT, NW, true, true> : flow_range2_kernel<H, L, NT, NW, true, false>)
-                   : (hl ? flow_range2_kernel<H, L, NT, NW, false, true> : flow_range2_kernel<H, L, NT, NW, false, false>);
+    auto kern = hf ? (hl ? flow_range2_kernel<H, L, NT, NW, true, true, PREC> : flow_range2_kernel<H, L, NT, NW, true, false, PREC>)
+                   : (hl ? flow_range2_kernel<H, L, NT, NW, false, true, PREC> : flow_range2_kernel<H, L, NT, NW, false, false, PREC>);
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_range2: cannot reserve %zu B of LDS", smem);
     const int64_t ngroups = (ra.f.N + 16 * NT - 1) / (16 * NT);
@@ -746,7 +746,7 @@ bool flow_range2_supported(int D, int L, int U, int nlayers) {
 int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, float* sum_log_det, float* log_prob, int64_t Mz,
                        int64_t Mp, int64_t N, int D, int S, int L, int U, const float* params, int64_t pstride,
                        const float* bn_mean, const float* bn_alpha, const float* interval_consts, unsigned* slow_count,
-                       int per_launch, hipStream_t st) {
+                       int per_launch, hipStream_t st, int prec) {
     const int nl = 2 * S;
     if (per_launch < 1) per_launch = 1;
     if (!flow_range2_supported(D, L, U, per_launch))
@@ -767,8 +767,14 @@ int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, flo
         // the conditioner half of the range's last layer must be written unless it is in zbuf already: a later launch of
         // ONE layer did not touch it (with more layers per launch the layer before transformed it inside the launch)
         ra.store_cond = (first || c_hi > c_lo) ? 1 : 0;
-        int rc = (D == 64) ? (L == 1 ? launch_range_t<32, 1>(ra, M, st) : (L == 2 ? launch_range_t<32, 2>(ra, M, st) : launch_range_t<32, 3>(ra, M, st)))
-                           : (L == 1 ? launch_range_t<16, 1>(ra, M, st) : (L == 2 ? launch_range_t<16, 2>(ra, M, st) : launch_range_t<16, 3>(ra, M, st)));
+        int rc;
+#define TNF_RANGE(HH, LL) rc = prec == 1 ? launch_range_t<HH, LL, 1>(ra, M, st) : launch_range_t<HH, LL, 0>(ra, M, st)
+        if (D == 64) {
+            if (L == 1) TNF_RANGE(32, 1); else if (L == 2) TNF_RANGE(32, 2); else TNF_RANGE(32, 3);
+        } else {
+            if (L == 1) TNF_RANGE(16, 1); else if (L == 2) TNF_RANGE(16, 2); else TNF_RANGE(16, 3);
+        }
+#undef TNF_RANGE
         if (rc != TNF_OK) return rc;
     }
     return check_launch("flow_chain2");

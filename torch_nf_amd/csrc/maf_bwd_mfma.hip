@@ -40,7 +40,7 @@ struct MafBLayout {  // group numbering shared by the folded image, the transpos
 // The (layer, net, out tile) units are dealt round-robin to the workgroup's `nwaves` waves: with one
 // workgroup per context the build is on the critical path of every context.
 __device__ void build_maf_bwd_images(float* fimg, float* timg, const float* __restrict__ p0, const float* __restrict__ mk0,
-                                     MafBLayout wl, int D, int U, int lane, int wave, int nwaves) {
+                                     MafBLayout wl, int D, int U, int lane, int wave, int nwaves, int bf) {
     const int r = lane & 15, q = lane >> 4;
     float* fw = fimg + lane * 4;
     float* fb = fimg + wl.NWG() * 256 + q * 4;
@@ -77,8 +77,8 @@ __device__ void build_maf_bwd_images(float* fimg, float* timg, const float* __re
                         const bool ok2 = k2 < din && o2 < dout;
                         vt[j] = ld_sel(w[net], k2 * dout + o2, ok2) * ld_sel(mk, k2 * dout + o2, ok2);
                     }
-                    *reinterpret_cast<f4*>(fw + (g_base + it) * 256) = vf;
-                    *reinterpret_cast<f4*>(tw + (g_base + it) * 256) = vt;
+                    *reinterpret_cast<f4*>(fw + (g_base + it) * 256) = rbf16_4(vf, bf);
+                    *reinterpret_cast<f4*>(tw + (g_base + it) * 256) = rbf16_4(vt, bf);
                 }
                 if (layer > 0) {  // accumulator initial values: column sums (there are no biases in MAF)
                     csum = reduce_q(csum);
@@ -131,6 +131,7 @@ struct MafBwdArgs {
     // max |g_lp| (gmax, float bits) into [1, 2) and fx = 2^f leaves 2^13 per accumulated term inside int32.
     const unsigned* gmax;
     float fx;
+    int bf16;  // != 0: the bf16 experiment (every MFMA operand rounded to bf16, mfma_tile.h rbf16)
 };
 
 constexpr int kMafLMax = 3;
@@ -179,7 +180,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
             for (int i = threadIdx.x; i < 7 * D; i += 256) cst[2 * D + i] = a.iv[i];
         for (int i = threadIdx.x; i < 2 * D + 1; i += 256) cst[9 * D + i] = 0.f;
     }
-    build_maf_bwd_images(fimg, timg, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4);
+    build_maf_bwd_images(fimg, timg, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4, a.bf16);
     __syncthreads();
 
     const float* fsrc = fimg + lane * 4;
@@ -263,6 +264,10 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
 
         // ---- 1. forward recompute, keeping r of every hidden level ----
         f4 r[kMafLMax][2][UT];
+        const int bf = a.bf16;
+        f4 xo[DT];  // the contraction operand (x itself, or its bf16 rounding)
+#pragma unroll
+        for (int mm = 0; mm < DT; ++mm) xo[mm] = rbf16_4(x[mm], bf);
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
             f4 at = zero, as = zero;
@@ -271,12 +276,12 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                 const f4 wt = wgrp(wl.g0(0, ut, mm)), ws = wgrp(wl.g0(1, ut, mm));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    at = mfma4(wt[j], x[mm][j], at);
-                    as = mfma4(ws[j], x[mm][j], as);
+                    at = mfma4(wt[j], xo[mm][j], at);
+                    as = mfma4(ws[j], xo[mm][j], as);
                 }
             }
-            r[0][0][ut] = sig2_4(at);
-            r[0][1][ut] = sig2_4(as);
+            r[0][0][ut] = rbf16_4(sig2_4(at), bf);
+            r[0][1][ut] = rbf16_4(sig2_4(as), bf);
         }
 #pragma unroll
         for (int l = 1; l < kMafLMax; ++l) {
@@ -293,8 +298,8 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                             as = mfma4(ws[j], r[l - 1][1][ui][j], as);
                         }
                     }
-                    r[l][0][uo] = sig2_4(at);
-                    r[l][1][uo] = sig2_4(as);
+                    r[l][0][uo] = rbf16_4(sig2_4(at), bf);
+                    r[l][1][uo] = rbf16_4(sig2_4(as), bf);
                 }
             }
         }
@@ -329,6 +334,8 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                 dlt[1][mo][j] = (16 * mo + 4 * q + j < D) ? (-ge * (x[mo][j] - mu[j]) + gl) : 0.f;
             }
             g[mo] = gz;  // from here on g holds g_z (direct path); the nets' share is added at layer 0
+            dlt[0][mo] = rbf16_4(dlt[0][mo], bf);
+            dlt[1][mo] = rbf16_4(dlt[1][mo], bf);
         }
 
         // ---- 3. layers back to front ----
@@ -347,7 +354,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
 #pragma unroll
                 for (int ui = 0; ui < UT; ++ui) {
                     const f4 hin = act_h(L, net, ui);
-                    const f4 h_t = maf_transpose(hin, scrB, lane);
+                    const f4 h_t = rbf16_4(maf_transpose(hin, scrB, lane), bf);
                     f4 acc = zero;
 #pragma unroll
                     for (int mo = 0; mo < DT; ++mo) {
@@ -361,7 +368,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                         for (int j = 0; j < 4; ++j) acc = mfma4(wb[j], dlt[net][mo][j], acc);
                     }
                     const f4 rv = (1.f - hin) * 0.5f;  // r
-                    dprev[net][ui] = acc * (4.f * rv * (1.f - rv));
+                    dprev[net][ui] = rbf16_4(acc * (4.f * rv * (1.f - rv)), bf);
                 }
             }
             // hidden layers L-1 .. 1
@@ -374,7 +381,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
 #pragma unroll
                         for (int ui = 0; ui < UT; ++ui) {
                             const f4 hin = act_h(lev, net, ui);
-                            const f4 h_t = maf_transpose(hin, scrB, lane);
+                            const f4 h_t = rbf16_4(maf_transpose(hin, scrB, lane), bf);
                             f4 acc = zero;
 #pragma unroll
                             for (int uo = 0; uo < UT; ++uo) {
@@ -388,7 +395,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
                                 for (int j = 0; j < 4; ++j) acc = mfma4(wb[j], dprev[net][uo][j], acc);
                             }
                             const f4 rv = (1.f - hin) * 0.5f;
-                            dnext[net][ui] = acc * (4.f * rv * (1.f - rv));
+                            dnext[net][ui] = rbf16_4(acc * (4.f * rv * (1.f - rv)), bf);
                         }
                     }
 #pragma unroll
@@ -400,7 +407,7 @@ maf_bwd_mfma_kernel(MafBwdArgs a, MafBLayout wl) {
             // layer 0: inputs = x (DT tiles), outputs = hidden level 0 (UT tiles)
 #pragma unroll
             for (int mm = 0; mm < DT; ++mm) {
-                const f4 x_t = maf_transpose(x[mm], scrB, lane);
+                const f4 x_t = maf_transpose(xo[mm], scrB, lane);
                 f4 acc = zero;
 #pragma unroll
                 for (int net = 0; net < 2; ++net) {
@@ -590,6 +597,7 @@ static int launch_maf_bwd_args(MafBwdArgs& a, hipStream_t st) {
     const int nacc = maf_bwd_nacc(a.D, a.L, a.U);
     const size_t smem = maf_bwd_smem(wl, nacc);
     a.nacc = nacc;
+    a.bf16 = g_operand_prec == 1;
     const int64_t ntiles = (a.N + 15) / 16;
     int64_t bx = (ntiles + 3) / 4;
     if (a.Mp > 1) bx = 1;  // one workgroup owns the context's gradient row: plain stores

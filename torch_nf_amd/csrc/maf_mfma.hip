@@ -36,7 +36,7 @@ struct MafLayout {
 // matrix per layer of the same shape.  One full wave builds the image (LDS destination).
 // The (layer, net, out tile) units are dealt round-robin to the workgroup's `nwaves` waves.
 __device__ void build_maf_image(float* img, const float* __restrict__ p, const float* __restrict__ mk, MafLayout wl,
-                                int D, int U, int lane, int wave, int nwaves) {
+                                int D, int U, int lane, int wave, int nwaves, int bf) {
     const int r = lane & 15, q = lane >> 4;
     int unit = 0;
     float* wdst = img + lane * 4;
@@ -56,7 +56,7 @@ __device__ void build_maf_image(float* img, const float* __restrict__ p, const f
                         const bool ok = f < D && u < U;
                         v[j] = kTwoLog2e * ld_sel(w[net], f * U + u, ok) * ld_sel(mk, f * U + u, ok);
                     }
-                    *reinterpret_cast<f4*>(wdst + wl.g_w0(net, ut, m) * 256) = v;
+                    *reinterpret_cast<f4*>(wdst + wl.g_w0(net, ut, m) * 256) = rbf16_4(v, bf);
                 }
             }
         p += 2 * D * U;
@@ -79,7 +79,7 @@ __device__ void build_maf_image(float* img, const float* __restrict__ p, const f
                         csum += raw;
                         v[j] = -2.f * kTwoLog2e * raw;
                     }
-                    *reinterpret_cast<f4*>(wdst + wl.g_wh(l, net, uo, ui) * 256) = v;
+                    *reinterpret_cast<f4*>(wdst + wl.g_wh(l, net, uo, ui) * 256) = rbf16_4(v, bf);
                 }
                 csum = reduce_q(csum);
                 f4 bv;
@@ -108,7 +108,7 @@ __device__ void build_maf_image(float* img, const float* __restrict__ p, const f
                         csum += raw;
                         v[j] = -2.f * sc * raw;
                     }
-                    *reinterpret_cast<f4*>(wdst + wl.g_w2(net, mo, ui) * 256) = v;
+                    *reinterpret_cast<f4*>(wdst + wl.g_w2(net, mo, ui) * 256) = rbf16_4(v, bf);
                 }
                 csum = reduce_q(csum);
                 f4 bv;
@@ -146,7 +146,7 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
         ivc[i] = (a.iv && f < D) ? a.iv[row * D + f] : 0.f;
     }
     const bool has_iv = a.iv != nullptr;
-    build_maf_image(img, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4);
+    build_maf_image(img, a.params + mp * a.pstride, a.masks, wl, D, U, lane, wave, 4, a.bf16);
     __syncthreads();
 
     const float* wsrc = img + lane * 4;
@@ -162,8 +162,10 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
     const float ldc = a.ldc ? a.ldc[mp] : 0.f;
 
     // twin nets on the tile's current iterate x -> mu (plain), al2 (alpha * log2 e)
-    auto nets = [&](const f4 (&x)[DT], f4 (&mu)[DT], f4 (&al2)[DT]) {
-        f4 rt[UT], rs[UT];
+    auto nets = [&](const f4 (&xin)[DT], f4 (&mu)[DT], f4 (&al2)[DT]) {
+        f4 rt[UT], rs[UT], x[DT];
+#pragma unroll
+        for (int mm = 0; mm < DT; ++mm) x[mm] = rbf16_4(xin[mm], a.bf16);
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
             f4 at = zero, as = zero;
@@ -176,8 +178,8 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
                     as = mfma4(ws[j], x[mm][j], as);
                 }
             }
-            rt[ut] = sig2_4(at);
-            rs[ut] = sig2_4(as);
+            rt[ut] = rbf16_4(sig2_4(at), a.bf16);
+            rs[ut] = rbf16_4(sig2_4(as), a.bf16);
         }
         for (int l = 0; l < wl.L - 1; ++l) {
             f4 nt[UT], ns[UT];
@@ -193,8 +195,8 @@ maf_mfma_kernel(MafArgs a, MafLayout wl) {
                         as = mfma4(ws[j], rs[ui][j], as);
                     }
                 }
-                nt[uo] = sig2_4(at);
-                ns[uo] = sig2_4(as);
+                nt[uo] = rbf16_4(sig2_4(at), a.bf16);
+                ns[uo] = rbf16_4(sig2_4(as), a.bf16);
             }
 #pragma unroll
             for (int u = 0; u < UT; ++u) {

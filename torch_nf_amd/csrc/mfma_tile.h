@@ -58,6 +58,20 @@ __device__ __forceinline__ float sig2(float a) {
 #endif
 }
 
+// The bf16 experiment on the fp32-MFMA kernels (TNF_OPT_OPERAND_PREC = 1): operands rounded to bf16 (RNE) and widened
+// back.  The products of two such values are exact in fp32, so feeding them to the fp32 MFMA reproduces a bf16 MFMA
+// with fp32 accumulation up to summation order -- the accuracy of a bf16 kernel, not its speed.  `on` is wave-uniform.
+__device__ __forceinline__ float rbf16(float v, int on) {
+    typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+    typedef float fv2 __attribute__((ext_vector_type(2)));
+    if (!on) return v;
+    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(fv2{v, 0.f}, bfv2));
+    return __builtin_bit_cast(float, u << 16);
+}
+__device__ __forceinline__ f4 rbf16_4(f4 v, int on) {
+    return f4{rbf16(v[0], on), rbf16(v[1], on), rbf16(v[2], on), rbf16(v[3], on)};
+}
+
 __device__ __forceinline__ f4 sig2_4(f4 v) {
     f4 r;
     r[0] = sig2(v[0]);

@@ -69,6 +69,7 @@ extern thread_local int g_flow_variant;   // flow_fused.hip
 extern thread_local int g_layer_variant;  // coupling_mfma.hip
 extern thread_local int g_train_bwd_fp32; // coupling_mfma.hip
 extern thread_local int g_cond_variant;   // cond_flow.hip
+extern thread_local int g_operand_prec;   // api.hip: 0 = fp32-accurate split-f16 operands, 1 = bf16 operands (experiment)
 
 // ---- kernels implemented in the .hip files ----------------------------------
 int launch_coupling_generic(int dtype, const void* z, const void* params, void* z_out,
@@ -134,7 +135,7 @@ bool flow_range2_supported(int D, int L, int U, int nlayers);
 int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, float* sum_log_det, float* log_prob, int64_t Mz,
                        int64_t Mp, int64_t N, int D, int S, int L, int U, const float* params, int64_t pstride,
                        const float* bn_mean, const float* bn_alpha, const float* interval_consts, unsigned* slow_count,
-                       int per_launch, hipStream_t st);
+                       int per_launch, hipStream_t st, int prec = 0);  // prec 1: the bf16 experiment (f16_tile2.h)
 // split-f16 variant of the whole-flow kernel (flow_fused_f16.hip); images in slots of mfma_image_floats(D, 3)
 int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,
                            int64_t pstride, hipStream_t st);
@@ -266,6 +267,7 @@ struct MafArgs {
     const float* iv;     // ToInterval constants (7, D) of a fused support layer, or NULL
     int64_t Mz, Mp, N;
     int D, L, U, inverse;
+    int bf16;            // != 0: the bf16 experiment (operands rounded to bf16, mfma_tile.h rbf16)
 };
 
 bool maf_mfma_supported(int D, int L, int U);

@@ -6,6 +6,9 @@ staged to the HIP device and results are handed back on the input's device, so
 code written against the reference (which is CPU-only) keeps working -- but the
 arithmetic always runs on the GPU; there is no CPU implementation here.
 """
+import contextlib
+import threading
+
 import torch
 
 from . import _lib
@@ -313,6 +316,32 @@ def base_log_density_f64(omega):
 # ---------------------------------------------------------------------------
 # flow level
 # ---------------------------------------------------------------------------
+_PREC_CODES = {"fp32": 0, "bf16": 1}
+_prec_state = threading.local()
+
+
+def current_operand_precision():
+    return getattr(_prec_state, "prec", "fp32")
+
+
+@contextlib.contextmanager
+def operand_precision(prec):
+    """The fp32-vs-bf16 experiment (BASELINE.json configs[4]): inside `operand_precision("bf16")` the RealNVP log_prob
+    kernels (flow_log_prob_raw and the forward leg of flow_log_prob_train) and the autoregressive-flow kernels (forward,
+    inverse and backward) round every conditioner operand to bf16.  Per thread, like every tnf_set_option key; autograd
+    runs backward on its own thread, so the Functions below record the precision their forward ran in and re-enter it.
+    Not a parity path: tools/bf16_sweep.py reports its error and its speed."""
+    code = _PREC_CODES[prec]
+    before = current_operand_precision()
+    check(lib.tnf_set_option(_lib.OPT_OPERAND_PREC, code))
+    _prec_state.prec = prec
+    try:
+        yield
+    finally:
+        check(lib.tnf_set_option(_lib.OPT_OPERAND_PREC, _PREC_CODES[before]))
+        _prec_state.prec = before
+
+
 def has_fast_path(D, L, U):
     return bool(lib.tnf_has_fast_path(D, L, U))
 
@@ -770,10 +799,16 @@ class _MafFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(z_out, params, masks)  # the sample: everything is evaluated there
         ctx.cfg = (D, L, U, inverse, z.shape[0])
+        ctx.prec = current_operand_precision()
         return z_out, log_det
 
     @staticmethod
     def backward(ctx, g_z, g_ld):
+        with operand_precision(ctx.prec):  # autograd's thread: re-enter the forward's operand precision
+            return _MafFn._backward(ctx, g_z, g_ld)
+
+    @staticmethod
+    def _backward(ctx, g_z, g_ld):
         from . import grad
 
         z, params, masks = ctx.saved_tensors
@@ -1080,6 +1115,7 @@ class _ArFlowLogProbFn(torch.autograd.Function):
                               _stats(bn_mean.reshape(-1), dev), _stats(bn_alpha.reshape(-1), dev))
         ctx.consts = interval_consts
         ctx.cfg = (D, L, U, pstride, params.device, tuple(params.shape))
+        ctx.prec = current_operand_precision()
         return lp
 
     @staticmethod
@@ -1093,11 +1129,12 @@ class _ArFlowLogProbFn(torch.autograd.Function):
         gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
         nbytes = check(lib.tnf_ar_flow_bwd_workspace_bytes(Mp, D))
         ws = _workspace(nbytes, dev)
-        check(lib.tnf_ar_flow_log_prob_bwd_f32(zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), mean.data_ptr(),
-                                               alpha.data_ptr(),
-                                               None if ctx.consts is None else ctx.consts.data_ptr(), g.data_ptr(),
-                                               gp.data_ptr(), M, Mp, N, D, L, U, pstride, gp.shape[1], ws.data_ptr(),
-                                               nbytes, _lib.stream_ptr()))
+        with operand_precision(ctx.prec):
+            check(lib.tnf_ar_flow_log_prob_bwd_f32(zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), mean.data_ptr(),
+                                                   alpha.data_ptr(),
+                                                   None if ctx.consts is None else ctx.consts.data_ptr(), g.data_ptr(),
+                                                   gp.data_ptr(), M, Mp, N, D, L, U, pstride, gp.shape[1], ws.data_ptr(),
+                                                   nbytes, _lib.stream_ptr()))
         return None, (gp if p_home == dev else gp.to(p_home)), None, None, None, None, None, None, None
 
 
