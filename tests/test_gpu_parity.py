@@ -46,7 +46,7 @@ def _force_generic(tnf, on):
 DEFAULT_FLOW_VARIANT = 10
 
 
-@pytest.fixture(params=[10, 15, 0], ids=["wholeflow_default", "wholeflow_f16split_v1", "wholeflow_f32mfma"])
+@pytest.fixture(params=[10, 20, 15, 0], ids=["wholeflow_f16split_16x16", "wholeflow_f16split_32x32", "wholeflow_f16split_v1", "wholeflow_f32mfma"])
 def flow_variant(request, tnf):
     """Run a test once per whole-flow kernel implementation (both sit behind TNF_FUSE_FLOW)."""
     tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_FLOW_VARIANT, request.param))

@@ -664,7 +664,10 @@ static int flow_log_prob_impl(const float* z, const float* params, const float* 
     const bool chain2 = !use_fused && narrow && g_layer_variant >= 10 && flow_range2_supported(D, L, U, 1);
     if (interval_consts && !f16 && !chain2)
         return fail(TNF_EUNSUPPORTED, "tnf_flow_log_prob_f32: a fused support layer needs the whole-flow kernel");
-    if (f16 && g_flow_variant == 10 && flow_fused2_supported(D, S, L, U))  // default: second formulation (f16_tile2.h)
+    if (f16 && g_flow_variant == 20 && flow_fused3_supported(D, S, L, U))  // 32-sample groups, 32x32x16 MFMAs (f16_tile3.h)
+        return launch_flow_fused3(z, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha,
+                                  interval_consts, exact_reruns, st);
+    if (f16 && (g_flow_variant == 10 || g_flow_variant == 20) && flow_fused2_supported(D, S, L, U))  // f16_tile2.h
         return launch_flow_fused2(z, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha,
                                   interval_consts, exact_reruns, st);
     if (f16)  // ONE launch: the flow kernel builds its split-f16 operands and folds BN / Affine in its prologue
@@ -937,7 +940,10 @@ int tnf_flow_log_prob_fwd_rev_f32(const float* z, const float* params, const flo
         return launch_flow_chain2(z, nullptr, nullptr, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, params, pstride, bn_mean,
                                   bn_alpha, nullptr, nullptr, 2 * S, as_stream(stream), 1);
     }
-    if (g_flow_variant == 10 && flow_fused2_supported(D, S, L, U))
+    if (g_flow_variant == 20 && flow_fused3_supported(D, S, L, U))
+        return launch_flow_fused3(z, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha, nullptr,
+                                  nullptr, as_stream(stream));
+    if ((g_flow_variant == 10 || g_flow_variant == 20) && flow_fused2_supported(D, S, L, U))
         return launch_flow_fused2(z, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha, nullptr,
                                   nullptr, as_stream(stream));
     return launch_flow_fused_f16(z, nullptr, nullptr, nullptr, z0, nullptr, log_prob, M, M_p, N, D, S, L, U, 1,

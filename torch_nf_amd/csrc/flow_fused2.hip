@@ -39,20 +39,6 @@
 
 namespace tnf {
 
-struct Flow2Args {
-    const float* z;
-    float* z_out;        // z0 (optional)
-    float* sum_log_det;  // optional
-    float* log_prob;     // optional
-    int64_t Mz, Mp, N;
-    int S, U;
-    const float* params;
-    const float* bn_mean;
-    const float* bn_alpha;
-    int64_t pstride, stage_stride, affine_off, low_off;
-    const float* iv;     // (7, D) constants of a fused ToInterval support layer, or NULL
-    unsigned* slow_count;  // optional: += number of groups re-run through the exact path (testing / diagnostics)
-};
 
 template <int H, int L>
 __host__ __device__ constexpr int flow2_lds_floats(int nl) {

@@ -126,11 +126,31 @@ int launch_flow_fused(const float* z, const float* images, const float* fold, co
                       int64_t N, int D, int S, int L, int U, int inverse, hipStream_t st);
 bool flow_fused_supported(int D, int S, int L, int U);
 // whole-flow inverse kernel, second formulation (flow_fused2.hip / f16_tile2.h)
+// arguments of the whole-flow inverse kernels (flow_fused2.hip, flow_fused3.hip)
+struct Flow2Args {
+    const float* z;
+    float* z_out;        // z0 (optional)
+    float* sum_log_det;  // optional
+    float* log_prob;     // optional
+    int64_t Mz, Mp, N;
+    int S, U;
+    const float* params;
+    const float* bn_mean;
+    const float* bn_alpha;
+    int64_t pstride, stage_stride, affine_off, low_off;
+    const float* iv;     // (7, D) constants of a fused ToInterval support layer, or NULL
+    unsigned* slow_count;  // optional: += number of groups re-run through the exact path (testing / diagnostics)
+};
+
 bool flow_fused2_supported(int D, int S, int L, int U);
 int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
                        int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
                        const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st);
 // the same tile code as a chain of launches with `per_launch` coupling layers each (1 = one kernel per coupling layer)
+bool flow_fused3_supported(int D, int S, int L, int U);  // flow_fused3.hip: the same on 32-sample groups (32x32x16 MFMAs)
+int launch_flow_fused3(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
+                       int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
+                       const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st);
 bool flow_range2_supported(int D, int L, int U, int nlayers);
 int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, float* sum_log_det, float* log_prob, int64_t Mz,
                        int64_t Mp, int64_t N, int D, int S, int L, int U, const float* params, int64_t pstride,
