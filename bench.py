@@ -335,11 +335,12 @@ def main():
         # f16 MFMA peak / 3.  (The kernel is not bound by it: sigmoids/exps and the operand splitting on the
         # vector pipe are -- DESIGN.md 3.4; the dense fp32 MFMA peak, 157.3 TFLOP/s, is already exceeded.)
         split_peak = F16_MFMA_TFLOPS / 3.0
-        traffic, stamp = read_traffic("flow_fused_f16_kernel") if D_ == 64 else (None, None)
+        traffic, stamp = read_traffic("flow_fused2_kernel") if D_ == 64 else (None, None)
         r = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3), "peak": round(split_peak, 1),
              "unit": "TFLOP/s", "frac": round(achieved / split_peak, 4), "traffic": traffic,
              "algorithmic_flop_per_sample": flops, "launch_ms": round(ev_mean, 4),
              "fp32_mfma_peak_tflops": F32_MFMA_TFLOPS, "frac_of_fp32_mfma_peak": round(achieved / F32_MFMA_TFLOPS, 4),
+             "algorithmic_bytes_per_launch": int(n * bytes_per_sample_chain(D_, 1)),
              "hbm_compulsory_frac": round(n * bytes_per_sample_chain(D_, 1) / (ev_mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if stamp is not None:
             r["traffic_source"] = stamp
@@ -348,9 +349,11 @@ def main():
     def chain_roofline(D_, evl_mean, n, kernel):
         k = 2 * S
         gbs = n * bytes_per_sample_chain(D_, k) / (evl_mean * 1e-3) / 1e9
-        traffic, stamp = read_traffic("coupling_mfma_kernel") if D_ == 64 else (None, None)
+        traffic, stamp = read_traffic("flow_range2_kernel") if D_ == 64 else (None, None)
         r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+             "traffic_is": "HBM bytes per launch, mean over the chain's launches (PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
+             "algorithmic_bytes_per_launch_mean": int(n * bytes_per_sample_chain(D_, k) / k),
              "algorithmic_bytes_per_sample_all_launches": bytes_per_sample_chain(D_, k)}
         if stamp is not None:
             r["traffic_source"] = stamp
@@ -361,7 +364,7 @@ def main():
     ev_mean = float(np.mean(ev))  # ms per call on the launch stream = the one kernel of the call (it builds its operands in its prologue)
     roofline = None
     if fused:
-        roofline = fused_roofline(D, ev_mean, N_PER_GPU, "flow_fused_f16_kernel<32,2,inverse,2,8,4>")
+        roofline = fused_roofline(D, ev_mean, N_PER_GPU, "flow_fused2_kernel<32,2,2,8,4>")
         roofline["note"] = ("achieved = algorithmic fp32 flops (42,176 per sample) / launch time; peak = dense f16 MFMA "
                             "peak (2,500 TFLOP/s) / 3, because each fp32-accurate contraction is issued as 3 split-f16 "
                             "MFMAs with fp32 accumulate; the binding unit is the vector pipe (sigmoids/exps + operand "
@@ -375,7 +378,7 @@ def main():
         "value": round(N_PER_GPU / (evl_mean * 1e-3) / 1e6, 2), "unit": "M samples/s", "launches": 2 * S,
         "ms_per_step": round(evl_mean, 4),
         "target_60pct_of_hbm_roof": round(0.6 * HBM_PEAK_GBS * 1e9 / bytes_per_sample_chain(D, 2 * S) / 1e6, 1),
-        "roofline": chain_roofline(D, evl_mean, N_PER_GPU, "coupling_mfma_kernel<32,2,inverse>"),
+        "roofline": chain_roofline(D, evl_mean, N_PER_GPU, "flow_range2_kernel<32,2,2,8,*,*,0> (one coupling layer per launch)"),
     }
     if roofline is None:
         roofline = layer_chain["roofline"]
@@ -426,9 +429,9 @@ def main():
         cfg["configs[1]"] = {
             "what": "NormFlow(32,False,'coupling',4,2,15).log_prob, z (1, 2^20, 32)",
             "value": round(N_PER_GPU / (m32 * 1e-3) / 1e6, 1), "unit": "M samples/s", "ms_per_step": round(m32, 4),
-            "roofline": fused_roofline(32, m32, N_PER_GPU, "flow_fused_f16_kernel<16,2,inverse,2,8,4>"),
+            "roofline": fused_roofline(32, m32, N_PER_GPU, "flow_fused2_kernel<16,2,2,8,4>"),
             "layer_chain": {"value": round(N_PER_GPU / (m32l * 1e-3) / 1e6, 1), "ms_per_step": round(m32l, 4),
-                            "roofline": chain_roofline(32, m32l, N_PER_GPU, "coupling_mfma_kernel<16,2,inverse>")}}
+                            "roofline": chain_roofline(32, m32l, N_PER_GPU, "flow_range2_kernel<16,2,2,8,*,*,0> (one coupling layer per launch)")}}
         del nf32, z32
         cfg["configs[2]"] = bench_rows.config2_row(tnf, dev)
         out["configs"] = cfg

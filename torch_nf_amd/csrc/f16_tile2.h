@@ -48,6 +48,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // hi = rne_f16(v), lo = rne_f16(v - hi) (the remainder is exact in fp32).  |v| >= 65520: hi = +-inf, lo = -+inf.
 __device__ __forceinline__ HiLo split2r(float v0, float v1) {
     const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{v0, v1}, h2));  // v_cvt_pk_f16_f32
+#if TNF2_ABL == 4  // timing experiment only: no remainder
+    return HiLo{hb, hb};
+#endif
     // in place ("+v"), never into a fresh register: the inline-asm rule of f16_tile.h
     asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(hb));
     asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(hb));
@@ -492,7 +495,11 @@ __device__ __forceinline__ void coupling_tile2(const float* img, int lane, const
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float s2 = sv[t][j];
+#if TNF2_ABL == 3  // timing experiment only: one log-det add per tile instead of eight
+                if (j == 0 && mo == 0) ssum2[t] += s2;
+#else
                 ssum2[t] += s2;
+#endif
                 y[t][mo][j] = __builtin_fmaf(y[t][mo][j], ay[j], -tt[t][j]) * __builtin_amdgcn_exp2f(-s2);
             }
     }

@@ -18,7 +18,7 @@
 // the scale comes out again when the gradients leave the kernel.
 //
 // A wave carries one 16-sample tile through all 2S layers, so the per-layer gradient accumulators
-// cannot live in registers: they are fixed-point ds_add_u32 targets in LDS (AccLayout, 2S x ~11.5 KB) and leave with one global atomic per parameter per workgroup.  That leaves
+// cannot live in registers: they are fixed-point ds_add_u32 targets in LDS (AccLayout, 2S x ~11 KB) and leave with one global atomic per parameter per workgroup.  That leaves
 // no room for all layers' operand images, so the waves of a workgroup step through the layers
 // together: the next layer's image (forward operands | transposed operands | fold constants,
 // ~21 KB, built once per call by flow_rev_images_kernel) is prefetched into registers during a
@@ -267,21 +267,30 @@ __device__ __forceinline__ f4 mm3(h4 wh, h4 wl, h4 xh, h4 xl, f4 acc) {
 // per layer.  fx is chosen on the host so that 2^13 per accumulated term cannot overflow (see launch_rev);
 // amax tracks the largest term so the kernel can tell when that budget did not hold.
 //
-// Accumulator layout of one layer (ints), hidden width padded to 16 and rows padded to an odd stride so that
-// the 64 lanes of a tile add without masks and with at most 2-way bank conflicts:
-//   W0 [net][f < H][17] | b0 [net][16] | { Wh [net][k_in < 16][17] | bh [net][16] } x (L-1) |
-//   W2 [net][k < 16][H+1] | b2 [net][H] | fold dA [D] | fold dB [D]
+// Accumulator layout of one layer (ints), hidden width padded to 16.  A 16 x 16 weight-gradient tile is stored in the
+// order its MFMA result sits in the registers: element (row r, column c) at word (c & 3) * 64 + (c >> 2) * 16 + r, i.e.
+// register j of lane l = (s, q) (row s, column 4q + j) at word j * 64 + l.  Each of a tile's four ds_add_u32 instructions
+// then touches 64 consecutive words: no bank conflicts, no padding, one base address and three immediate offsets.
+// (Round 1 stored rows with an odd stride of 17 / H + 1 words: two-way conflicts on most banks, SQ_LDS_BANK_CONFLICT more
+// than half of the LDS-active cycles in profiles/r01_g_pmc_flow_bwd.json.)
+//   W0 tiles [net][mm] (rows = features 16 mm + r, columns = units) | b0 [net][16] |
+//   { Wh tiles [net] (rows = units in, columns = units out) | bh [net][16] } x (L-1) |
+//   W2 tiles [net][mo] (rows = units, columns = features 16 mo + c) | b2 [net][H] | fold dA [D] | fold dB [D]
 template <int H, int L>
 struct AccLayout {
-    static constexpr int US = 17, HS = H + 1;
+    static constexpr int HT = H / 16, TILE = 256;
     static constexpr int o_w0 = 0;
-    static constexpr int o_b0 = o_w0 + 2 * H * US;
+    static constexpr int o_b0 = o_w0 + 2 * HT * TILE;
     static constexpr int o_h = o_b0 + 32;
-    static constexpr int HID = 2 * 16 * US + 32;
+    static constexpr int HID = 2 * TILE + 32;
     static constexpr int o_w2 = o_h + (L - 1) * HID;
-    static constexpr int o_b2 = o_w2 + 2 * 16 * HS;
+    static constexpr int o_b2 = o_w2 + 2 * HT * TILE;
     static constexpr int o_fold = o_b2 + 2 * H;
     static constexpr int INTS = (o_fold + 4 * H + 3) & ~3;
+    __host__ __device__ static constexpr int word(int r, int c) { return (c & 3) * 64 + (c >> 2) * 16 + r; }
+    __host__ __device__ static constexpr int w0(int net, int f, int u) { return o_w0 + (net * HT + (f >> 4)) * TILE + word(f & 15, u); }
+    __host__ __device__ static constexpr int wh(int l, int net, int k, int u) { return o_h + l * HID + net * TILE + word(k, u); }
+    __host__ __device__ static constexpr int w2(int net, int k, int f) { return o_w2 + (net * HT + (f >> 4)) * TILE + word(k, f & 15); }
 };
 
 struct FxAcc {
@@ -299,15 +308,15 @@ __device__ __forceinline__ int fx_cvt(float scaled) {
     asm("v_cvt_rpi_i32_f32 %0, %0" : "+v"(scaled));  // floor(x + 0.5), saturating; the int replaces the float's bits
     return __builtin_bit_cast(int, scaled);
 }
-// all four values of every lane are real (padded entries receive exact zeros)
+// one tile (AccLayout): p = tile + lane; all four values of every lane are real (padded entries receive exact zeros)
 __device__ __forceinline__ void lds_add4(int* p, f4 v, FxAcc& fa) {
     const float t0 = v[0] * fa.fx, t1 = v[1] * fa.fx, t2 = v[2] * fa.fx, t3 = v[3] * fa.fx;
     fa.amax = amax3(fa.amax, t0, t1);
     fa.amax = amax3(fa.amax, t2, t3);
     atomicAdd(p + 0, fx_cvt(t0));
-    atomicAdd(p + 1, fx_cvt(t1));
-    atomicAdd(p + 2, fx_cvt(t2));
-    atomicAdd(p + 3, fx_cvt(t3));
+    atomicAdd(p + 64, fx_cvt(t1));
+    atomicAdd(p + 128, fx_cvt(t2));
+    atomicAdd(p + 192, fx_cvt(t3));
 }
 // a row-sum tile holds the same four sums (rows 4q + j) in every sample lane: lanes s < 4 add row 4q + s
 __device__ __forceinline__ void lds_add_rows(int* p4q, f4 v, int s, FxAcc& fa) {
@@ -345,7 +354,7 @@ template <int H, int L, bool SPARE>
 __device__ __forceinline__ int acc_src(int kk, int U) {
     typedef AccLayout<H, L> A_;
     if (kk < 2 * H * U + 2 * U) {
-        if (kk < 2 * H * U) return A_::o_w0 + (kk / U) * A_::US + kk % U;   // (net, f) rows are contiguous
+        if (kk < 2 * H * U) return A_::w0(kk / (H * U), (kk / U) % H, kk % U);
         return A_::o_b0 + ((kk - 2 * H * U) / U) * 16 + (kk - 2 * H * U) % U;
     }
     kk -= 2 * H * U + 2 * U;
@@ -354,17 +363,17 @@ __device__ __forceinline__ int acc_src(int kk, int U) {
         const int l = kk / hs, r = kk - l * hs;
         if (r < 2 * U * U) {
             const int net = r / (U * U), rr = r - net * U * U;
-            return A_::o_h + l * A_::HID + (net * 16 + rr / U) * A_::US + rr % U;
+            return A_::wh(l, net, rr / U, rr % U);
         }
-        if (SPARE) return A_::o_h + l * A_::HID + (((r - 2 * U * U) / U) * 16 + 15) * A_::US + (r - 2 * U * U) % U;
-        return A_::o_h + l * A_::HID + 2 * 16 * A_::US + ((r - 2 * U * U) / U) * 16 + (r - 2 * U * U) % U;
+        if (SPARE) return A_::wh(l, (r - 2 * U * U) / U, 15, (r - 2 * U * U) % U);
+        return A_::o_h + l * A_::HID + 2 * A_::TILE + ((r - 2 * U * U) / U) * 16 + (r - 2 * U * U) % U;
     }
     kk -= (L - 1) * hs;
     if (kk < 2 * U * H) {
         const int net = kk / (U * H), rr = kk - net * U * H;
-        return A_::o_w2 + (net * 16 + rr / H) * A_::HS + rr % H;
+        return A_::w2(net, rr / H, rr % H);
     }
-    if (SPARE) return A_::o_w2 + (((kk - 2 * U * H) / H) * 16 + 15) * A_::HS + (kk - 2 * U * H) % H;
+    if (SPARE) return A_::w2((kk - 2 * U * H) / H, 15, (kk - 2 * U * H) % H);
     return A_::o_b2 + (kk - 2 * U * H);
 }
 
@@ -378,22 +387,22 @@ struct LdsFxAccum {
     FxAcc& fa;
     int s, q;
     __device__ __forceinline__ void w2(int net, int mo, const T16& d_t, const T16& h_t) {
-        lds_add4(acc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mo + 4 * q, outer16h(d_t, h_t), fa);
+        lds_add4(acc + A_::o_w2 + (net * A_::HT + mo) * A_::TILE + 16 * q + s, outer16h(d_t, h_t), fa);
     }
     __device__ __forceinline__ void b2(int net, int mo, const T16& d_t) {
         lds_add_rows(acc + A_::o_b2 + net * H + 16 * mo + 4 * q, rowsum16h(d_t), s, fa);
     }
     __device__ __forceinline__ void wh(int l, int net, const T16& d_t, const T16& h_t) {
-        lds_add4(acc + A_::o_h + l * A_::HID + (net * 16 + s) * A_::US + 4 * q, outer16h(d_t, h_t), fa);
+        lds_add4(acc + A_::o_h + l * A_::HID + net * A_::TILE + 16 * q + s, outer16h(d_t, h_t), fa);
     }
     __device__ __forceinline__ void bh(int l, int net, const T16& d_t) {
-        lds_add_rows(acc + A_::o_h + l * A_::HID + 2 * 16 * A_::US + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
+        lds_add_rows(acc + A_::o_h + l * A_::HID + 2 * A_::TILE + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
     }
     __device__ __forceinline__ void b0(int net, const T16& d_t) {
         lds_add_rows(acc + A_::o_b0 + net * 16 + 4 * q, rowsum16h(d_t), s, fa);
     }
     __device__ __forceinline__ void w0(int net, int mm, const T16& d_t, const T16& x_t) {
-        lds_add4(acc + A_::o_w0 + (net * H + 16 * mm + s) * A_::US + 4 * q, outer16h(d_t, x_t), fa);
+        lds_add4(acc + A_::o_w0 + (net * A_::HT + mm) * A_::TILE + 16 * q + s, outer16h(d_t, x_t), fa);
     }
 };
 
@@ -1047,6 +1056,10 @@ coupling_bwd_f16_kernel(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) p[j] += v[j];
     };
+    auto add_tile = [&](float* tile, f4 v) {  // AccLayout tile: register j of this lane at word j * 64 + lane
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[j * 64 + lane] += v[j];
+    };
     auto red16 = [&](float v) -> float {
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
@@ -1060,14 +1073,14 @@ coupling_bwd_f16_kernel(BwdArgs a) {
             for (int net = 0; net < 2; ++net) {
 #pragma unroll
                 for (int mm = 0; mm < HT; ++mm) {
-                    add4(gacc + A_::o_w0 + (net * H + 16 * mm + s) * A_::US + 4 * q, ra.W0[net][mm]);
-                    add4(gacc + A_::o_w2 + (net * 16 + s) * A_::HS + 16 * mm + 4 * q, ra.W2[net][mm]);
+                    add_tile(gacc + A_::o_w0 + (net * HT + mm) * A_::TILE, ra.W0[net][mm]);
+                    add_tile(gacc + A_::o_w2 + (net * HT + mm) * A_::TILE, ra.W2[net][mm]);
                     if (!SPARE && s == 0) add4(gacc + A_::o_b2 + net * H + 16 * mm + 4 * q, ra.B2[net][mm]);
                 }
 #pragma unroll
                 for (int l = 0; l < L - 1; ++l) {
-                    add4(gacc + A_::o_h + l * A_::HID + (net * 16 + s) * A_::US + 4 * q, ra.Wh[l][net]);
-                    if (!SPARE && s == 0) add4(gacc + A_::o_h + l * A_::HID + 2 * 16 * A_::US + net * 16 + 4 * q, ra.Bh[l][net]);
+                    add_tile(gacc + A_::o_h + l * A_::HID + net * A_::TILE, ra.Wh[l][net]);
+                    if (!SPARE && s == 0) add4(gacc + A_::o_h + l * A_::HID + 2 * A_::TILE + net * 16 + 4 * q, ra.Bh[l][net]);
                 }
                 if (s == 0) add4(gacc + A_::o_b0 + net * 16 + 4 * q, ra.B0[net]);
             }
@@ -1151,7 +1164,8 @@ static int64_t rev_image_floats(int D, int L) {
 
 static int64_t rev_lds_bytes(int D, int S, int L, int U) {
     const int H = D / 2;
-    const int64_t ACC = (2 * H * 17 + 32 + (int64_t)(L - 1) * (2 * 16 * 17 + 32) + 2 * 16 * (H + 1) + 2 * H + 4 * H + 3) & ~3LL;
+    const int64_t HT = H / 16;
+    const int64_t ACC = (2 * HT * 256 + 32 + (int64_t)(L - 1) * (2 * 256 + 32) + 2 * HT * 256 + 2 * H + 4 * H + 3) & ~3LL;
     (void)U;
     return (2 * rev_image_floats(D, L) + 2 * S * ACC + (int64_t)kRevNW * kRevNScr * kScr) * 4;
 }
