@@ -312,14 +312,39 @@ def main():
                 allreduce_gradients([p_train], average=True)
             opt.step()
 
-        for _ in range(2):
-            train_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            train_step()
-        barrier()
-        train_ms = max_over_ranks(time.perf_counter() - t0) / 5 * 1e3
+        def time_train(reps=10):
+            for _ in range(2):
+                train_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                train_step()
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0) / reps * 1e3
+
+        train_ms = time_train()
+        # the same step without the host read-back of the backward's fixed-point overflow flag (ops._FlowLogProbRevFn:
+        # the read-back is what lets a step whose accumulators overflowed fall back to the fp32 kernels; it costs a
+        # host synchronisation per step), and -- single GPU -- replayed as ONE HIP graph (no host work at all)
+        from torch_nf_amd import ops as _ops
+        _ops._FlowLogProbRevFn.check_overflow = False
+        train_ms_nosync = time_train()
+        _ops._FlowLogProbRevFn.check_overflow = True
+        train_ms_graph = None
+        if world == 1:
+            try:
+                opt = torch.optim.Adam([p_train], lr=1e-4, capturable=True)
+                gs = tnf.graphs.GraphedStep(train_step, warmup=3)
+                for _ in range(2):
+                    gs()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    gs()
+                barrier()
+                train_ms_graph = (time.perf_counter() - t0) / 10 * 1e3
+            except RuntimeError as e:  # capture unavailable: the eager numbers stand
+                train_ms_graph = "unavailable: " + str(e).splitlines()[0][:120]
         nf.params = nf_params_saved
 
     if rank != 0:
@@ -352,7 +377,8 @@ def main():
         traffic, stamp = read_traffic("flow_range2_kernel") if D_ == 64 else (None, None)
         r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-             "traffic_is": "HBM bytes per launch, mean over the chain's launches (PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
+             "traffic_is": "HBM bytes per launch, mean over the chain's launches (PMC: 2 x FETCH_SIZE + WRITE_SIZE); it is "
+                           "BELOW the SURVEY 8(d) figure because an in-place launch stores only the half it transformed",
              "algorithmic_bytes_per_launch_mean": int(n * bytes_per_sample_chain(D_, k) / k),
              "algorithmic_bytes_per_sample_all_launches": bytes_per_sample_chain(D_, k)}
         if stamp is not None:
@@ -411,6 +437,8 @@ def main():
         "strong_scaling": strong,
         "train_step": None if train_ms is None else {
             "ms": round(train_ms, 3), "samples_per_gpu": 1 << 19,
+            "ms_without_overflow_readback": round(train_ms_nosync, 3),
+            "ms_as_one_hip_graph": train_ms_graph if not isinstance(train_ms_graph, float) else round(train_ms_graph, 3),
             "value": round((1 << 19) * world / (train_ms * 1e-3) / 1e6, 1), "unit": "M samples/s",
             "what": "loss = -mean(log_prob): whole-flow forward keeping z0, one-kernel reversible backward (split-f16 MFMA); "
                     + ("RCCL all-reduce of the flat gradient (81,856 B, one bucket); " if world > 1 else "") + "Adam step"},
