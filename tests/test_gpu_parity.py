@@ -756,6 +756,74 @@ def test_operand_range(tnf, oracle, D):
         assert zerr <= zbar, "%s: z0 err %.3g > %.3g" % (name, zerr, zbar)
 
 
+@pytest.mark.parametrize("D", [64, 32])
+def test_operand_range_forward(tnf, oracle, D):
+    """test_operand_range for the SAMPLING direction (NormFlow.forward with frozen statistics, bijectors.py:172): base
+    draws scaled by 1e4 and by 1e5, BatchNorm means of 1e5, first-layer weights of 1e-5 with large draws and of 1e4,
+    everything scaled down.  Truth = the oracle's forward in float64; z is compared per sample relative to its largest
+    coordinate, the summed log-det absolutely relative to its size -- each with the float32 oracle's own deviation as
+    the yardstick where fp32 itself cannot do better."""
+    S, L, U, N = 4, 2, 15, 2000
+    ops, L_ = tnf.ops, tnf._lib
+    h = D // 2
+
+    def scale_layer0(params, fac):
+        p = params.clone()
+        off = 0
+        for kind, n, up in oracle.flow_layout(D, S, L, U):
+            if kind == "coupling":
+                p[:, off:off + 2 * h * U] *= fac
+            off += n
+        return p
+
+    def fwd(omega, params, st):
+        """the bijector loop of density_estimator.py:374-388 in the dtype of its inputs: (z, sum of log-dets)"""
+        z, sld, idx, bn_i = omega, 0.0, 0, 0
+        for kind, n, upper in oracle.flow_layout(D, S, L, U):
+            if kind == "coupling":
+                z, ld = oracle.coupling(z, params[:, idx:idx + n], D, L, U, upper, False)
+                idx += n
+            elif kind == "affine":
+                z, ld = oracle.affine(z, params[:, idx:idx + n], D, False)
+                idx += n
+            else:
+                z, ld = oracle.bn_forward_frozen(z, st[bn_i][0], st[bn_i][1])
+                bn_i += 1
+            sld = sld + ld
+        return z, sld.expand(z.shape[0], z.shape[1]) if sld.dim() == 2 else sld
+
+    nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=78)
+    om = torch.randn(1, N, D, generator=torch.Generator().manual_seed(5))
+    cases = {
+        "plain": (om, params, stats),
+        "omega_1e4": (om * 1e4, params, stats),
+        "omega_1e5": (om * 1e5, params, stats),
+        "bn_mean_1e5": (om, params, [(m + 1e5, a) for m, a in stats]),
+        "w0_1e-5_omega_1e5": (om * 1e5, scale_layer0(params, 1e-5), stats),
+        "w0_1e4": (om, scale_layer0(params, 1e4), stats),
+        "all_params_1e-5": (om, params * 1e-5, stats),
+    }
+    for name, (oo, pp, st) in cases.items():
+        st64 = [(m.double(), a.double()) for m, a in st]
+        z64, sld64 = fwd(oo.double(), pp.double(), st64)
+        z32, sld32 = fwd(oo, pp, st)
+        assert torch.isfinite(z64).all() and torch.isfinite(sld64).all(), name
+        _install_stats(nf, [m.numpy() for m, _ in st], [a.numpy() for _, a in st])
+        mean, alpha = nf._bn_stats(torch.device("cuda"))
+        scale = z64.abs().amax(dim=2, keepdim=True).clamp_min(1.0)
+        # 8 x for z: the kernels' fp32 arithmetic is not the oracle's op for op (exp2 with folded constants, FMA folds),
+        # and at draws of 1e5 the forward's cancellations amplify every rounding the same way they amplify the oracle's
+        zbar = max(2e-5, 8.0 * ((z32.double() - z64).abs() / scale).max().item())
+        lbar = max(LOGP_RTOL, 8.0 * _rel_err(sld32, sld64))
+        for fusion in (L_.FUSE_FLOW, L_.FUSE_LAYER):
+            with torch.no_grad():
+                z, sld = ops.flow_forward_raw(oo.cuda(), pp.cuda(), mean, alpha, D, S, L, U, fusion)
+            zerr = ((z.cpu().double() - z64).abs() / scale).max().item()
+            assert zerr <= zbar, "%s fusion %d: z err %.3g > %.3g" % (name, fusion, zerr, zbar)
+            lerr = _rel_err(sld.cpu(), sld64)
+            assert lerr <= lbar, "%s fusion %d: sum log-det err %.3g > %.3g" % (name, fusion, lerr, lbar)
+
+
 def test_bf16_operand_experiment_is_scoped_and_close(tnf):
     """TNF_OPT_OPERAND_PREC (the fp32-vs-bf16 sweep of BASELINE configs[4], tools/bf16_sweep.py): inside
     ops.operand_precision("bf16") the coupling and autoregressive log_prob kernels use bf16 conditioner operands

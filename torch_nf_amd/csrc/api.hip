@@ -1150,6 +1150,9 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
     const bool f16 = use_fused && g_flow_variant >= 10;
     if (interval_consts && !f16)
         return fail(TNF_EUNSUPPORTED, "tnf_flow_forward_f32: a fused support layer needs the whole-flow kernel");
+    if (f16 && (g_flow_variant == 10 || g_flow_variant == 20) && flow_fused2_supported(D, S, L, U))  // f16_tile2.h, FWD
+        return launch_flow_fused2(omega, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha,
+                                  interval_consts, nullptr, st, 1);
     if (f16)
         return launch_flow_fused_f16(omega, nullptr, nullptr, nullptr, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L,
                                      U, 0, g_flow_variant, st, params, pstride, bn_mean, bn_alpha, interval_consts);

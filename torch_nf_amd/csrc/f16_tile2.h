@@ -26,6 +26,12 @@
 //    contraction NaN; the NaN reaches the tile's log-det sum, the kernel sees it once per tile and re-runs that tile
 //    with the first layer's contraction in exact fp32 MFMAs (weights rebuilt as hi + lo, inputs not split at all).
 //
+// FORWARD direction (sampling, FWD = true): the same machinery with the maps AFTER the layers.  Registers x~, y~ with true
+//    values Px x~ and Py y~ (per-feature affine maps); the layer emits  y~' = fma(fma(y~, Ay, By), 2^s', t')  with
+//    Ay = Py_A sigma, By = Py_B sigma (By cannot ride in t's bias: it meets the scale), t' = t sigma; the fold F behind the
+//    layer stays pending on both halves: next layer's conditioner map (F_A / sigma, F_B) is absorbed by its layer-0
+//    weights, the other half's F o Px becomes its Py.  The caller passes foldc = F_{c-1}, foldprev = F_{c-2}.
+//
 // 4. A compiler hazard found on the way (hipcc / ROCm 7.2, gfx950) and avoided by construction: a
 //    v_mfma_f32_16x16x16_f16 whose SrcC is the result of a v_mfma_f32_16x16x32_f16 (or the other way round) gets too
 //    few wait states -- the accumulator is read before the first MFMA has written it, and results change from run to
@@ -124,8 +130,8 @@ struct Img2 {
     static constexpr int OFF_D = N0 * 256;          // [g][lane] 16 B: [w_hi(4) | w_lo(4)]
     static constexpr int OFF_B = OFF_D + NK * 256;  // [g][q][4] fp32 biases (accumulator initial values)
     static constexpr int OFF_S = OFF_B + NBG * 16;  // 8 floats: sigmoid scales S[stage][net]
-    static constexpr int OFF_A = OFF_S + 8;         // H floats: Ay * sigma of the transformed half
-    static constexpr int FLOATS = OFF_A + H;
+    static constexpr int OFF_A = OFF_S + 8;         // H floats: Ay * sigma of the transformed half; H more: By * sigma (forward)
+    static constexpr int FLOATS = OFF_A + 2 * H;
     __device__ static constexpr int k_l0(int net) { return net; }  // H == 16 only
     __device__ static constexpr int k_h(int l, int net) { return ((H == 16) ? 2 : 0) + 2 * l + net; }
     __device__ static constexpr int k_o(int net, int mo) { return ((H == 16) ? 2 : 0) + 2 * (L - 1) + net * HT + mo; }
@@ -177,7 +183,7 @@ __device__ __forceinline__ void store_k16(u4* gd, const float (&v)[4]) {
 //   sc_in    2^kappa_k: the conditioner registers hold (true value before foldc) / sc_in
 //   sc_prev  2^kappa_{k-1} (ignored when foldprev == NULL)
 //   sig_next 2^-kappa_{k+1}: factor the transformed half is emitted with (1 for the last layer walked)
-template <int H, int L, int PREC = 0>
+template <int H, int L, int PREC = 0, bool FWD = false>
 __device__ __forceinline__ void build_image2(float* img, const float* __restrict__ p, int U, int lane, const float* foldc,
                                              const float* foldprev, int c, float sc_in, float sc_prev, float sig_next) {
     typedef Img2<H, L> I;
@@ -219,7 +225,7 @@ __device__ __forceinline__ void build_image2(float* img, const float* __restrict
             for (int j = 0; j < 4; ++j) w.wh[l][net][j] *= S;
         }
     // output layer: the t-net also carries sig_next and (through its bias) the pending B of the transformed half
-    f4 ays[HT];
+    f4 ays[HT], bys[HT];
 #pragma unroll
     for (int mo = 0; mo < HT; ++mo)
 #pragma unroll
@@ -229,7 +235,9 @@ __device__ __forceinline__ void build_image2(float* img, const float* __restrict
             const float Ap = foldprev ? foldprev[toff + f] * sc_prev : 1.f;
             const float Bp = foldprev ? foldprev[D + toff + f] : 0.f;
             ays[mo][j] = Ac * Ap * sig_next;
-            w.b2[0][mo][j] = (w.b2[0][mo][j] - __builtin_fmaf(Ac, Bp, Bc)) * sig_next;
+            bys[mo][j] = __builtin_fmaf(Ac, Bp, Bc) * sig_next;
+            if constexpr (FWD) w.b2[0][mo][j] *= sig_next;
+            else w.b2[0][mo][j] = (w.b2[0][mo][j] - __builtin_fmaf(Ac, Bp, Bc)) * sig_next;
         }
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
@@ -295,7 +303,10 @@ __device__ __forceinline__ void build_image2(float* img, const float* __restrict
             for (int mo = 0; mo < HT; ++mo) *reinterpret_cast<f4*>(bl + I::b_b2(net, mo) * 16) = w.b2[net][mo];
         }
 #pragma unroll
-        for (int mo = 0; mo < HT; ++mo) *reinterpret_cast<f4*>(img + I::OFF_A + 16 * mo + 4 * q) = ays[mo];
+        for (int mo = 0; mo < HT; ++mo) {
+            *reinterpret_cast<f4*>(img + I::OFF_A + 16 * mo + 4 * q) = ays[mo];
+            *reinterpret_cast<f4*>(img + I::OFF_A + H + 16 * mo + 4 * q) = bys[mo];
+        }
     }
     if (lane == 0) {
 #pragma unroll
@@ -373,9 +384,10 @@ __device__ __forceinline__ void coupling_tile2_bf16(const float* img, int lane, 
     }
 }
 
-template <int H, int L, int NT, bool SLOW, int PREC = 0>
+template <int H, int L, int NT, bool SLOW, int PREC = 0, bool FWD = false>
 __device__ __forceinline__ void coupling_tile2(const float* img, int lane, const f4 (&x)[NT][H / 16], f4 (&y)[NT][H / 16],
                                                float (&ssum2)[NT]) {
+    static_assert(!(FWD && PREC == 1), "the bf16 experiment covers the inverse direction");
     if constexpr (PREC == 1) {
         coupling_tile2_bf16<H, L, NT>(img, lane, x, y, ssum2);
         return;
@@ -490,6 +502,8 @@ __device__ __forceinline__ void coupling_tile2(const float* img, int lane, const
             for (int t = 0; t < NT; ++t) sv[t] = contract16(wv, rh[t][1], rl[t][1], b2);
         }
         const f4 ay = *reinterpret_cast<const f4*>(img + I::OFF_A + 16 * mo + 4 * (lane >> 4));
+        f4 by = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (FWD) by = *reinterpret_cast<const f4*>(img + I::OFF_A + H + 16 * mo + 4 * (lane >> 4));
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -500,7 +514,10 @@ __device__ __forceinline__ void coupling_tile2(const float* img, int lane, const
 #else
                 ssum2[t] += s2;
 #endif
-                y[t][mo][j] = __builtin_fmaf(y[t][mo][j], ay[j], -tt[t][j]) * __builtin_amdgcn_exp2f(-s2);
+                if constexpr (FWD)
+                    y[t][mo][j] = __builtin_fmaf(__builtin_fmaf(y[t][mo][j], ay[j], by[j]), __builtin_amdgcn_exp2f(s2), tt[t][j]);
+                else
+                    y[t][mo][j] = __builtin_fmaf(y[t][mo][j], ay[j], -tt[t][j]) * __builtin_amdgcn_exp2f(-s2);
             }
     }
 }

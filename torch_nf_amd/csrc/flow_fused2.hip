@@ -42,16 +42,29 @@ namespace tnf {
 
 template <int H, int L>
 __host__ __device__ constexpr int flow2_lds_floats(int nl) {
-    // images | fold (nl, 2, D) | fin [A (H) | B (H)] | kappa (nl ints) pad 16 | queue head (4) | red (16) | iv (7 D)
-    return nl * Img2<H, L>::FLOATS + nl * 4 * H + 2 * H + ((nl + 3) / 4) * 4 + 4 + 16 + 7 * 2 * H;
+    // images | fold (nl + 1, 2, D) | fin [A (D) | B (D)] | kappa (nl ints) pad 16 | queue head (4) | red (16) | iv (7 D)
+    return nl * Img2<H, L>::FLOATS + (nl + 1) * 4 * H + 4 * H + ((nl + 3) / 4) * 4 + 4 + 16 + 7 * 2 * H;
 }
 
 // all coupling layers of one group of NT tiles; lo / hi: the two halves of the registers (see f16_tile2.h)
-template <int H, int L, int NT, int SS, bool SLOW>
+template <int H, int L, int NT, int SS, bool SLOW, bool FWD = false>
 __device__ __forceinline__ void run_layers2(const float* img, int S, int lane, f4 (&lo)[NT][H / 16], f4 (&hi)[NT][H / 16],
                                             float (&ssum)[NT]) {
     typedef Img2<H, L> I;
-    if constexpr (SS > 0 && !SLOW) {
+    if constexpr (FWD) {  // sampling direction: layer 2 st conditions on the lower half, 2 st + 1 on the upper
+        if constexpr (SS > 0 && !SLOW) {
+#pragma unroll
+            for (int st = 0; st < SS; ++st) {
+                coupling_tile2<H, L, NT, false, 0, true>(img + (2 * st) * I::FLOATS, lane, lo, hi, ssum);
+                coupling_tile2<H, L, NT, false, 0, true>(img + (2 * st + 1) * I::FLOATS, lane, hi, lo, ssum);
+            }
+        } else {
+            for (int st = 0; st < S; ++st) {
+                coupling_tile2<H, L, NT, SLOW, 0, true>(img + (2 * st) * I::FLOATS, lane, lo, hi, ssum);
+                coupling_tile2<H, L, NT, SLOW, 0, true>(img + (2 * st + 1) * I::FLOATS, lane, hi, lo, ssum);
+            }
+        }
+    } else if constexpr (SS > 0 && !SLOW) {
 #pragma unroll
         for (int i = 0; i < SS; ++i) {
             const int st = SS - 1 - i;
@@ -66,7 +79,10 @@ __device__ __forceinline__ void run_layers2(const float* img, int S, int lane, f
     }
 }
 
-template <int H, int L, int NT, int NWAVES, int SS = 0>
+// FWD = false: the inverse pass (z -> z0, log_prob), walking layers 2S-1 .. 0 with the folds in FRONT of the layers.
+// FWD = true: the sampling pass (omega -> z, sum of log-dets), walking 0 .. 2S-1 with the folds BEHIND the layers:
+// fold slot c holds the map in front of layer c in the walk -- slot 0 the identity, slot c the forward fold of layer c-1.
+template <int H, int L, int NT, int NWAVES, int SS = 0, bool FWD = false>
 __global__ void __launch_bounds__(NWAVES * 64)
 flow_fused2_kernel(Flow2Args a) {
     constexpr int D = 2 * H;
@@ -75,9 +91,9 @@ flow_fused2_kernel(Flow2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nl = 2 * a.S;
     float* img = lds;
-    float* fold = lds + nl * I::FLOATS;          // [nl][A (D) | B (D)]
-    float* fin = fold + nl * 2 * D;              // [A (H) | B (H)] pending map of the lower half after the last layer
-    int* kap = reinterpret_cast<int*>(fin + 2 * H);  // [nl] kappa per layer index c
+    float* fold = lds + nl * I::FLOATS;          // [nl + 1][A (D) | B (D)]
+    float* fin = fold + (nl + 1) * 2 * D;        // [A (D) | B (D)] maps still pending after the last layer walked
+    int* kap = reinterpret_cast<int*>(fin + 2 * D);  // [nl] kappa per layer index c
     int* qhead = kap + ((nl + 3) / 4) * 4;
     float* red = reinterpret_cast<float*>(qhead + 4);  // [16] partial log-det constants
     float* ivc = red + 16;                             // [7][D]
@@ -106,10 +122,18 @@ flow_fused2_kernel(Flow2Args a) {
                 ea = expf(av);
                 shift = ap[D + d];
             }
-            const float A = alpha / ea;
-            fold[c * 2 * D + d] = A;
-            fold[c * 2 * D + D + d] = mu - shift * A;
+            if constexpr (FWD) {  // A = e^a / alpha_bn, B = shift - mean_bn A, behind layer c: slot c + 1
+                const float A = ea / alpha;
+                fold[(c + 1) * 2 * D + d] = A;
+                fold[(c + 1) * 2 * D + D + d] = shift - mu * A;
+            } else {
+                const float A = alpha / ea;
+                fold[c * 2 * D + d] = A;
+                fold[c * 2 * D + D + d] = mu - shift * A;
+            }
         }
+        if constexpr (FWD)
+            for (int i = threadIdx.x; i < 2 * D; i += NWAVES * 64) fold[i] = i < D ? 1.f : 0.f;
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         if (lane == 0) red[wave] = acc;
         if (threadIdx.x == 0) *qhead = NWAVES;
@@ -123,18 +147,41 @@ flow_fused2_kernel(Flow2Args a) {
         if (lane == 0) kap[c] = kc;
     }
     __syncthreads();
-    // ---- prologue C: operand images; pending map of the lower half after the last layer (c = 0) ----
+    // ---- prologue C: operand images; the maps still pending after the last layer walked ----
     for (int c = wave; c < nl; c += NWAVES) {
         const float sc_in = pow2i(kap[c]);
-        const bool first = (c == nl - 1), last = (c == 0);
-        const float sc_prev = first ? 1.f : pow2i(kap[c + 1]);
-        const float sig_next = last ? 1.f : pow2i(-kap[c - 1]);
-        build_image2<H, L>(img + c * I::FLOATS, prow + (c >> 1) * a.stage_stride + (c & 1) * a.low_off, a.U, lane,
-                           fold + c * 2 * D, first ? nullptr : fold + (c + 1) * 2 * D, c, sc_in, sc_prev, sig_next);
+        const float* pl = prow + (c >> 1) * a.stage_stride + (c & 1) * a.low_off;
+        if constexpr (FWD) {
+            // walk order 0 .. nl-1: layer c-1 was walked before c; the fold in front of layer c is slot c, the one the
+            // transformed half still owes from two layers back slot c-1 (slot 0 = identity, so c = 1 is regular)
+            const float sc_prev = c > 0 ? pow2i(kap[c - 1]) : 1.f;
+            const float sig_next = c < nl - 1 ? pow2i(-kap[c + 1]) : 1.f;
+            build_image2<H, L, 0, true>(img + c * I::FLOATS, pl, a.U, lane, fold + c * 2 * D,
+                                        c > 0 ? fold + (c - 1) * 2 * D : nullptr, c, sc_in, sc_prev, sig_next);
+        } else {
+            const bool first = (c == nl - 1), last = (c == 0);
+            const float sc_prev = first ? 1.f : pow2i(kap[c + 1]);
+            const float sig_next = last ? 1.f : pow2i(-kap[c - 1]);
+            build_image2<H, L>(img + c * I::FLOATS, pl, a.U, lane, fold + c * 2 * D,
+                               first ? nullptr : fold + (c + 1) * 2 * D, c, sc_in, sc_prev, sig_next);
+        }
     }
-    for (int f = threadIdx.x; f < H; f += NWAVES * 64) {
-        fin[f] = fold[f] * pow2i(kap[0]);
-        fin[H + f] = fold[D + f];
+    if constexpr (FWD) {
+        // the last layer (c = nl-1, odd) transformed the lower half (true values) and conditioned on the upper one, whose
+        // registers still carry 2^kappa and the fold of slot nl-1; slot nl (behind the last layer) is owed by both
+        const float* fl = fold + nl * 2 * D;
+        const float* fp = fold + (nl - 1) * 2 * D;
+        const float sc = pow2i(kap[nl - 1]);
+        for (int f = threadIdx.x; f < D; f += NWAVES * 64) {
+            const bool up = f >= H;
+            fin[f] = up ? fl[f] * fp[f] * sc : fl[f];
+            fin[D + f] = up ? __builtin_fmaf(fl[f], fp[D + f], fl[D + f]) : fl[D + f];
+        }
+    } else {
+        for (int f = threadIdx.x; f < H; f += NWAVES * 64) {
+            fin[f] = fold[f] * pow2i(kap[0]);
+            fin[D + f] = fold[D + f];
+        }
     }
     const bool has_iv = a.iv != nullptr;
     __syncthreads();
@@ -142,7 +189,8 @@ flow_fused2_kernel(Flow2Args a) {
 #if TNF2_PRIO
     if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 64 * (NWAVES / 2)) __builtin_amdgcn_s_setprio(1);
 #endif
-    const float presc = pow2i(-kap[nl - 1]);  // the first layer walked (c = nl-1, odd) conditions on the upper half
+    // the first layer walked conditions on the upper half (inverse: c = nl-1) / the lower half (forward: c = 0)
+    const float presc = pow2i(-kap[FWD ? 0 : nl - 1]);
     const float* zb = a.z + mz * a.N * D;
     float* zo = a.z_out ? a.z_out + m * a.N * D : nullptr;
     float* sldo = a.sum_log_det ? a.sum_log_det + m * a.N : nullptr;
@@ -172,41 +220,55 @@ flow_fused2_kernel(Flow2Args a) {
         }
     };
     // support layer (first bijector of the inverse pass) and the first layer's input scale
-    auto enter = [&](f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssup)[NT]) {
-        if (has_iv) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int mm = 0; mm < HT; ++mm)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float o, l;
-                        interval_fast<true>(dlo[t][mm][j], ivc, D, 16 * mm + 4 * q + j, o, l);
-                        dlo[t][mm][j] = o;
-                        ssup[t] += l;
-                        interval_fast<true>(dhi[t][mm][j], ivc, D, H + 16 * mm + 4 * q + j, o, l);
-                        dhi[t][mm][j] = o;
-                        ssup[t] += l;
-                    }
-        }
+    auto support = [&](auto inv, f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssup)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int mm = 0; mm < HT; ++mm)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dhi[t][mm][j] *= presc;
+                for (int j = 0; j < 4; ++j) {
+                    float o, l;
+                    interval_fast<decltype(inv)::value>(dlo[t][mm][j], ivc, D, 16 * mm + 4 * q + j, o, l);
+                    dlo[t][mm][j] = o;
+                    ssup[t] += l;
+                    interval_fast<decltype(inv)::value>(dhi[t][mm][j], ivc, D, H + 16 * mm + 4 * q + j, o, l);
+                    dhi[t][mm][j] = o;
+                    ssup[t] += l;
+                }
     };
-    // registers -> true values of the lower half (the upper half leaves the last layer as a true value)
-    auto leave = [&](f4 (&dlo)[NT][HT]) {
+    auto enter = [&](f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssup)[NT]) {
+        if (!FWD && has_iv) support(std::true_type{}, dlo, dhi, ssup);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (FWD) dlo[t][mm][j] *= presc;
+                    else dhi[t][mm][j] *= presc;
+                }
+    };
+    // registers -> true values: inverse, the lower half (the upper half leaves the last layer as a true value);
+    // forward, both halves (the fold behind the last layer), then the support layer
+    auto leave = [&](f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssup)[NT]) {
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
             const f4 fa = *reinterpret_cast<const f4*>(fin + 16 * mm + 4 * q);
-            const f4 fb = *reinterpret_cast<const f4*>(fin + H + 16 * mm + 4 * q);
+            const f4 fb = *reinterpret_cast<const f4*>(fin + D + 16 * mm + 4 * q);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dlo[t][mm][j] = __builtin_fmaf(dlo[t][mm][j], fa[j], fb[j]);
+            if constexpr (FWD) {
+                const f4 ga = *reinterpret_cast<const f4*>(fin + H + 16 * mm + 4 * q);
+                const f4 gb = *reinterpret_cast<const f4*>(fin + D + H + 16 * mm + 4 * q);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dhi[t][mm][j] = __builtin_fmaf(dhi[t][mm][j], ga[j], gb[j]);
+            }
         }
+        if (FWD && has_iv) support(std::false_type{}, dlo, dhi, ssup);
     };
 
     f4 nlo[NT][HT], nhi[NT][HT];
@@ -231,7 +293,7 @@ flow_fused2_kernel(Flow2Args a) {
         }
         enter(lo, hi, ssup);
         if (has_next) load_group(nxt, nlo, nhi);
-        run_layers2<H, L, NT, SS, false>(img, a.S, lane, lo, hi, ssum);
+        run_layers2<H, L, NT, SS, false, FWD>(img, a.S, lane, lo, hi, ssum);
         // an input beyond the f16 range of its (scaled) operand turned into NaN and reached the log-det sum:
         // re-run this group with exact first-layer contractions (also taken, harmlessly, by genuine NaN inputs)
         float chk = ssum[0];
@@ -245,16 +307,16 @@ flow_fused2_kernel(Flow2Args a) {
                 ssup[t] = 0.f;
             }
             enter(lo, hi, ssup);
-            run_layers2<H, L, NT, 0, true>(img, a.S, lane, lo, hi, ssum);
+            run_layers2<H, L, NT, 0, true, FWD>(img, a.S, lane, lo, hi, ssum);
             if (a.slow_count && lane == 0) atomicAdd(a.slow_count, 1u);
         }
-        leave(lo);
+        leave(lo, hi, ssup);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int64_t row = (grp * NT + t) * 16 + s;
             const bool row_ok = row < a.N;
             const float ld_tot = __builtin_fmaf(reduce_q(ssum[t]), kLn2, ldc) + (has_iv ? reduce_q(ssup[t]) : 0.f);
-            if (lpo) {
+            if (!FWD && lpo) {
                 float sq = 0.f;
 #pragma unroll
                 for (int mm = 0; mm < HT; ++mm)
@@ -662,10 +724,10 @@ bool flow_fused2_supported(int D, int S, int L, int U) {
     return flow2_lds_bytes_rt(D, S, L) <= 160 * 1024;
 }
 
-template <int H, int L, int NT, int NW, int SS>
+template <int H, int L, int NT, int NW, int SS, bool FWD>
 static int launch2_t(const Flow2Args& a, int64_t M, hipStream_t st) {
     const size_t smem = flow2_lds_bytes<H, L>(a.S);
-    auto kern = flow_fused2_kernel<H, L, NT, NW, SS>;
+    auto kern = flow_fused2_kernel<H, L, NT, NW, SS, FWD>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_fused2: cannot reserve %zu B of LDS", smem);
     const int64_t ngroups = (a.N + 16 * NT - 1) / (16 * NT);
@@ -677,17 +739,18 @@ static int launch2_t(const Flow2Args& a, int64_t M, hipStream_t st) {
 }
 
 template <int H, int L>
-static int launch2_v(const Flow2Args& a, int64_t M, hipStream_t st) {
+static int launch2_v(const Flow2Args& a, int64_t M, int forward, hipStream_t st) {
     // the reference's usual depth (num_stages = 4): layer loop fully unrolled
 #if TNF2_UNROLL
-    if (a.S == 4) return launch2_t<H, L, TNF2_NT, TNF2_NW, 4>(a, M, st);
+    if (a.S == 4) return forward ? launch2_t<H, L, TNF2_NT, TNF2_NW, 4, true>(a, M, st) : launch2_t<H, L, TNF2_NT, TNF2_NW, 4, false>(a, M, st);
 #endif
-    return launch2_t<H, L, TNF2_NT, TNF2_NW, 0>(a, M, st);
+    return forward ? launch2_t<H, L, TNF2_NT, TNF2_NW, 0, true>(a, M, st) : launch2_t<H, L, TNF2_NT, TNF2_NW, 0, false>(a, M, st);
 }
 
 int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
                        int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
-                       const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st) {
+                       const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st,
+                       int forward) {
     if (!flow_fused2_supported(D, S, L, U))
         return fail(TNF_EUNSUPPORTED, "flow_fused2: no kernel for D=%d S=%d L=%d U=%d", D, S, L, U);
     if (N <= 0) return TNF_OK;
@@ -696,8 +759,8 @@ int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log
     Flow2Args a{z, z0, sum_log_det, log_prob, Mz, Mp, N, S, U, params, bn_mean, bn_alpha, pstride, fl.stage,
                 fl.p_up + fl.p_low, fl.p_up, interval_consts, slow_count};
     int rc;
-    if (D == 64) rc = L == 1 ? launch2_v<32, 1>(a, M, st) : (L == 2 ? launch2_v<32, 2>(a, M, st) : launch2_v<32, 3>(a, M, st));
-    else rc = L == 1 ? launch2_v<16, 1>(a, M, st) : (L == 2 ? launch2_v<16, 2>(a, M, st) : launch2_v<16, 3>(a, M, st));
+    if (D == 64) rc = L == 1 ? launch2_v<32, 1>(a, M, forward, st) : (L == 2 ? launch2_v<32, 2>(a, M, forward, st) : launch2_v<32, 3>(a, M, forward, st));
+    else rc = L == 1 ? launch2_v<16, 1>(a, M, forward, st) : (L == 2 ? launch2_v<16, 2>(a, M, forward, st) : launch2_v<16, 3>(a, M, forward, st));
     if (rc != TNF_OK) return rc;
     return check_launch("flow_fused2");
 }

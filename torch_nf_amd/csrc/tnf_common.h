@@ -143,9 +143,11 @@ struct Flow2Args {
 };
 
 bool flow_fused2_supported(int D, int S, int L, int U);
+// forward = 0: inverse pass (z -> z0, sum of log-dets, log_prob); 1: sampling pass (omega -> z in z0, sum of log-dets)
 int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
                        int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
-                       const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st);
+                       const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st,
+                       int forward = 0);
 // the same tile code as a chain of launches with `per_launch` coupling layers each (1 = one kernel per coupling layer)
 bool flow_fused3_supported(int D, int S, int L, int U);  // flow_fused3.hip: the same on 32-sample groups (32x32x16 MFMAs)
 int launch_flow_fused3(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
