@@ -323,13 +323,16 @@ def main():
             return max_over_ranks(time.perf_counter() - t0) / reps * 1e3
 
         train_ms = time_train()
-        # the same step without the host read-back of the backward's fixed-point overflow flag (ops._FlowLogProbRevFn:
-        # the read-back is what lets a step whose accumulators overflowed fall back to the fp32 kernels; it costs a
-        # host synchronisation per step), and -- single GPU -- replayed as ONE HIP graph (no host work at all)
+        # the same step with the other overflow-recovery modes of the backward (ops._FlowLogProbRevFn.overflow_recovery):
+        # default "device" = the fp32 recomputation is always enqueued, its kernels gated on the device-side flag;
+        # "host" = read the flag back (a host synchronisation per step); "off" = no recovery (NaN poison stands);
+        # and -- single GPU -- the default step replayed as ONE HIP graph (no host work at all)
         from torch_nf_amd import ops as _ops
-        _ops._FlowLogProbRevFn.check_overflow = False
-        train_ms_nosync = time_train()
-        _ops._FlowLogProbRevFn.check_overflow = True
+        _ops._FlowLogProbRevFn.overflow_recovery = "off"
+        train_ms_off = time_train()
+        _ops._FlowLogProbRevFn.overflow_recovery = "host"
+        train_ms_host = time_train()
+        _ops._FlowLogProbRevFn.overflow_recovery = "device"
         train_ms_graph = None
         if world == 1:
             try:
@@ -437,7 +440,8 @@ def main():
         "strong_scaling": strong,
         "train_step": None if train_ms is None else {
             "ms": round(train_ms, 3), "samples_per_gpu": 1 << 19,
-            "ms_without_overflow_readback": round(train_ms_nosync, 3),
+            "overflow_recovery": "device-gated fp32 recomputation (default)",
+            "ms_recovery_off": round(train_ms_off, 3), "ms_recovery_by_host_readback": round(train_ms_host, 3),
             "ms_as_one_hip_graph": train_ms_graph if not isinstance(train_ms_graph, float) else round(train_ms_graph, 3),
             "value": round((1 << 19) * world / (train_ms * 1e-3) / 1e6, 1), "unit": "M samples/s",
             "what": "loss = -mean(log_prob): whole-flow forward keeping z0, one-kernel reversible backward (split-f16 MFMA); "

@@ -75,6 +75,16 @@ enum {
 };
 int tnf_set_option(int32_t key, int32_t value);
 
+/* Conditionally needed launches.  While a gate is set (per thread; NULL clears it), the layer kernels launched by
+ * tnf_flow_log_prob_fwd_f32 / tnf_flow_log_prob_bwd_f32 read *flag on the device and return at once while it is 0:
+ * the calls can be enqueued unconditionally behind a kernel that may or may not raise the flag, with no host round trip.
+ * Used for the fp32 recomputation of a training backward whose fixed-point accumulators overflowed
+ * (tnf_flow_log_prob_bwd_rev_f32's `overflow`): torch_nf_amd/ops.py:_FlowLogProbRevFn.  The small preparation kernels of
+ * those calls run regardless (they write private workspace only).
+ * tnf_gated_copy_f32: dst[0..n) = src[0..n) if *flag != 0, nothing otherwise. */
+int tnf_set_launch_gate(const int32_t* flag);
+int tnf_gated_copy_f32(const int32_t* flag, float* dst, const float* src, int64_t n, void* stream);
+
 /* Number of packed parameters of one RealNVP layer / of the whole coupling flow.
  * Replaces RealNVP.count_num_params (bijectors.py:244-262) and
  * NormFlow.count_num_params (density_estimator.py:418-421) for arch_type

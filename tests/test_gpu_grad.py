@@ -412,15 +412,47 @@ def test_flow_reversible_backward_overflow_falls_back(tnf, oracle):
     p_ref = p0.clone().requires_grad_()
     (-oracle.flow_log_prob(z0, p_ref, D, S, L, U, stats).sum()).backward()
     fn = tnf.ops._FlowLogProbRevFn
-    before = fn.overflow_fallbacks
-    p = p0.cuda().requires_grad_()
     z = z0.cuda()
-    assert nf._train_path(z, p) == "reversible"
-    (-nf.log_prob(z, p).sum()).backward()
-    assert fn.overflow_fallbacks == before + 1, "the fixed-point budget must have been exceeded by this input"
-    assert bool(torch.isfinite(p.grad).all())
     scale = float(p_ref.grad.abs().max())
-    torch.testing.assert_close(p.grad.cpu() / scale, p_ref.grad / scale, rtol=2e-3, atol=2e-5)
+    try:
+        # "host": the flag is read back and the fp32 pair launched when set
+        fn.overflow_recovery = "host"
+        before = fn.overflow_fallbacks
+        p = p0.cuda().requires_grad_()
+        assert nf._train_path(z, p) == "reversible"
+        (-nf.log_prob(z, p).sum()).backward()
+        assert fn.overflow_fallbacks == before + 1, "the fixed-point budget must have been exceeded by this input"
+        assert bool(torch.isfinite(p.grad).all())
+        torch.testing.assert_close(p.grad.cpu() / scale, p_ref.grad / scale, rtol=2e-3, atol=2e-5)
+        g_host = p.grad.clone()
+        # "device" (the default): the same recomputation enqueued unconditionally, its kernels gated on the flag on the
+        # device -- same gradient, no host round trip; and a well-behaved batch leaves the flag clear and the
+        # one-kernel backward's own (bit-reproducible) result in place
+        fn.overflow_recovery = "device"
+        p = p0.cuda().requires_grad_()
+        zg = z.clone().requires_grad_()
+        (-nf.log_prob(zg, p).sum()).backward()
+        assert int(fn.last_overflow_flag.item()) == 1
+        # (the fp32 pair ends in float atomics: equal to the last bits, not bit for bit)
+        torch.testing.assert_close(p.grad / scale, g_host / scale, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(p.grad.cpu() / scale, p_ref.grad / scale, rtol=2e-3, atol=2e-5)
+        assert bool(torch.isfinite(zg.grad).all())
+        z_ok = torch.tensor(rng.normal(0, 1, (1, N, D))).float().cuda()
+        grads = []
+        for mode in ("device", "off"):
+            fn.overflow_recovery = mode
+            p = p0.cuda().requires_grad_()
+            (-nf.log_prob(z_ok, p).sum()).backward()
+            grads.append(p.grad.clone())
+        assert int(fn.last_overflow_flag.item()) == 0
+        assert torch.equal(grads[0], grads[1])
+        # "off": the poison stands
+        fn.overflow_recovery = "off"
+        p = p0.cuda().requires_grad_()
+        (-nf.log_prob(z, p).sum()).backward()
+        assert bool(torch.isnan(p.grad).any())
+    finally:
+        fn.overflow_recovery = "device"
     # ... and the raw C call alone reports the overflow and poisons its rows instead of returning a wrapped sum
     lib, L_ = tnf._lib.lib, tnf._lib
     mean, alpha = nf._bn_stats(torch.device("cuda"))

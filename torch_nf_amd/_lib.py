@@ -27,6 +27,8 @@ SIGNATURES = {
     "tnf_version": (ctypes.c_int, []),
     "tnf_last_error": (ctypes.c_char_p, []),
     "tnf_set_option": (ctypes.c_int, [_i32, _i32]),
+    "tnf_set_launch_gate": (ctypes.c_int, [_vp]),
+    "tnf_gated_copy_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "tnf_coupling_num_params": (_i64, [_i32, _i32, _i32, _i32]),
     "tnf_flow_num_params": (_i64, [_i32, _i32, _i32, _i32]),
     "tnf_has_fast_path": (ctypes.c_int, [_i32, _i32, _i32]),

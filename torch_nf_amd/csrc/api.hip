@@ -8,6 +8,7 @@ namespace tnf {
 
 thread_local int g_force_generic = 0;
 thread_local int g_operand_prec = 0;
+thread_local const int* g_launch_gate = nullptr;
 
 char* err_buf() {
     static thread_local char buf[512] = {0};
@@ -68,6 +69,27 @@ extern "C" {
 int tnf_version(void) { return TNF_VERSION; }
 
 const char* tnf_last_error(void) { return err_buf(); }
+
+int tnf_set_launch_gate(const int32_t* flag) {
+    g_launch_gate = reinterpret_cast<const int*>(flag);
+    return TNF_OK;
+}
+
+__global__ void __launch_bounds__(256)
+gated_copy_kernel(const int* __restrict__ gate, float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    if (*gate == 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+int tnf_gated_copy_f32(const int32_t* flag, float* dst, const float* src, int64_t n, void* stream) {
+    if (!flag || !dst || !src || n < 0) return fail(TNF_EINVAL, "tnf_gated_copy_f32: NULL pointer or n=%lld", (long long)n);
+    if (n == 0) return TNF_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gated_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const int*>(flag), dst, src, n);
+    return check_launch("gated_copy");
+}
 
 int tnf_set_option(int32_t key, int32_t value) {
     if (key == TNF_OPT_FORCE_GENERIC) {
@@ -831,6 +853,7 @@ int tnf_flow_log_prob_fwd_f32(const float* z, const float* params, const float* 
         a.log_prob = last ? log_prob : nullptr;
         a.Mz = M; a.Mp = M_p; a.N = N;
         a.D = D; a.L = L; a.U = U; a.upper = (c & 1) ? 0 : 1; a.inverse = 1;
+        a.gate = g_launch_gate;
         rc = launch_coupling_mfma(a, st);
         if (rc) return rc;
     }
@@ -891,6 +914,7 @@ int tnf_flow_log_prob_bwd_f32(const float* z, const float* states, const float* 
         a.g_lp = (c == 0) ? g_log_prob : nullptr;
         a.glp_sum = glp_sum;
         a.gmax = gmaxw;
+        a.gate = g_launch_gate;
         // split-f16 layer backward unless asked otherwise or it would spill (L = 3 without a spare unit)
         if (g_train_bwd_fp32 || (L == 3 && U > 15)) rc = launch_coupling_backward_mfma_args(a, D, L, 1, st);
         else rc = launch_coupling_backward_f16(a, D, L, 1, st);

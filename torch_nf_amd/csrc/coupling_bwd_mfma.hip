@@ -121,6 +121,7 @@ __device__ __forceinline__ f4 outer16(f4 a_t, f4 b_t, f4 acc) {
 template <int H, int L, bool INV>
 __global__ void __launch_bounds__(256)
 coupling_bwd_mfma_kernel(BwdArgs a) {
+    if (a.gate && *a.gate == 0) return;  // a conditionally needed launch (tnf_set_launch_gate): nothing to do
     constexpr int D = 2 * H;
     constexpr int HT = (H + 15) / 16;
     constexpr int LH = (L > 1) ? (L - 1) : 1;

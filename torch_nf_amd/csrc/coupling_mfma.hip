@@ -180,6 +180,7 @@ int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_
 template <int H, int L, bool INV, int NT, bool LDSOP>
 __global__ void __launch_bounds__(256)
 coupling_mfma_kernel(MfmaLayerArgs a) {
+    if (a.gate && *a.gate == 0) return;  // a conditionally needed launch (tnf_set_launch_gate): nothing to do
     constexpr int D = 2 * H;
     constexpr int HT = (H + 15) / 16;
     typedef LdsLayerImage<H, L> Img;

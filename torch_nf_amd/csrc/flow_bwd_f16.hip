@@ -906,6 +906,7 @@ constexpr int kLayerNW = 8;
 template <int H, int L, bool SPARE, bool INV>
 __global__ void __launch_bounds__(kLayerNW * 64)
 coupling_bwd_f16_kernel(BwdArgs a) {
+    if (a.gate && *a.gate == 0) return;  // a conditionally needed launch (tnf_set_launch_gate): nothing to do
     typedef RevImage<H, L> R;
     typedef AccLayout<H, L> A_;
     constexpr int D = 2 * H;

@@ -69,6 +69,7 @@ extern thread_local int g_flow_variant;   // flow_fused.hip
 extern thread_local int g_layer_variant;  // coupling_mfma.hip
 extern thread_local int g_train_bwd_fp32; // coupling_mfma.hip
 extern thread_local int g_cond_variant;   // cond_flow.hip
+extern thread_local const int* g_launch_gate;  // api.hip: tnf_set_launch_gate
 extern thread_local int g_operand_prec;   // api.hip: 0 = fp32-accurate split-f16 operands, 1 = bf16 operands (experiment)
 
 // ---- kernels implemented in the .hip files ----------------------------------
@@ -101,6 +102,7 @@ struct MfmaLayerArgs {
     int wave_m;  // set by the launcher: one context (m) per wave instead of per workgroup (many contexts, few samples)
     int skip_cond_store;  // in-place chains (z_out == z): leave the conditioner half in memory as it is -- the fold this
                           // kernel applied to it is composed into the next kernel's constants (flow_fold_kernel, chain = 1)
+    const int* gate;      // optional device flag: the kernel returns at once while *gate == 0 (tnf_set_launch_gate)
 };
 int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st);
 
@@ -234,6 +236,7 @@ struct BwdArgs {
                           // the kernel works on gradients scaled by the power of two that brings it into [1, 2)
     const float* gcorr;   // [k0 (D) | k1 (D)] or NULL: the upstream gradient is g_zout + k0 + k1 * (this layer's output)
                           // (batch-statistics backward of the fold behind the layer, forward direction only)
+    const int* gate;      // optional device flag: the kernel returns at once while *gate == 0 (tnf_set_launch_gate)
 };
 int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);
 int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, int inverse, hipStream_t st);  // split-f16 (flow_bwd_f16.hip)

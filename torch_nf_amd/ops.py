@@ -651,12 +651,20 @@ class _FlowLogProbRevFn(torch.autograd.Function):
     makes the parameter gradient reproducible bit for bit).  A gradient term beyond their budget -- a heavy-tailed
     sample, whose deltas also approach the f16 range of the split operands -- is flagged by the kernel (its own result
     is NaN then, never a wrapped sum), and the step is recomputed through the per-layer pair with fp32 layer kernels
-    (tnf_flow_log_prob_fwd_f32 / _bwd_f32, no such budget).  Reading the flag costs one host round trip per backward;
-    `check_overflow = False` (or a HIP-graph capture, where the flag cannot be read) skips it: such a step then
-    yields a NaN gradient instead of the fallback's."""
+    (tnf_flow_log_prob_fwd_f32 / _bwd_f32, no such budget).  `overflow_recovery` says how:
+      "device" (default)  the recomputation is enqueued behind the backward unconditionally, gated on the flag ON THE
+                          DEVICE (tnf_set_launch_gate): its layer kernels return at once while the flag is clear, a
+                          gated copy moves its gradients over the poisoned ones when it is set.  No host round trip, so
+                          it also works inside a HIP-graph capture; costs ~20 empty launches and the fallback's buffers.
+      "host"              the flag is read back (one synchronisation per backward) and the recomputation launched only
+                          when needed; under a capture the flag cannot be read and the NaN poison stands.
+      "off"               no recovery: an overflowing step yields a NaN gradient.
+    `check_overflow = False` is the old spelling of "off"."""
 
     check_overflow = True
-    overflow_fallbacks = 0  # how often the fp32 pair had to take over (diagnostic)
+    overflow_recovery = "device"
+    overflow_fallbacks = 0  # "host" mode: how often the fp32 pair had to take over (diagnostic)
+    last_overflow_flag = None  # "device" mode: the flag tensor of the latest backward (diagnostic, read it after a sync)
 
     @staticmethod
     def forward(ctx, z, params, bn_mean, bn_alpha, D, S, L, U):
@@ -687,18 +695,35 @@ class _FlowLogProbRevFn(torch.autograd.Function):
         gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
         ws_bytes = check(lib.tnf_flow_train_rev_workspace_bytes(M, Mp, N, D, S, L, U))
         ws = _workspace(ws_bytes, dev)
-        look = _FlowLogProbRevFn.check_overflow and not torch.cuda.is_current_stream_capturing()
-        flag = torch.zeros(1, dtype=torch.int32, device=dev) if look else None
+        mode = _FlowLogProbRevFn.overflow_recovery if _FlowLogProbRevFn.check_overflow else "off"
+        if mode != "off" and not flow_train_supported(M, Mp, N, D, S, L, U):
+            mode = "off"  # no per-layer pair for this shape: the poison is all there is
+        if mode == "host" and torch.cuda.is_current_stream_capturing():
+            mode = "off"
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode != "off" else None
         check(lib.tnf_flow_log_prob_bwd_rev_f32(z0.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
                                                 g.data_ptr(), gz.data_ptr() if gz is not None else None,
                                                 gp.data_ptr(), M, Mp, N, D, S, L, U, pstride, gp.shape[1],
                                                 ws.data_ptr(), ws.numel(), None if flag is None else flag.data_ptr(),
                                                 _lib.stream_ptr()))
-        if flag is not None and int(flag.item()) != 0 and flow_train_supported(M, Mp, N, D, S, L, U):
+        if mode == "host" and int(flag.item()) != 0:
             # a term left the fixed-point budget: the same step through the per-layer pair, fp32 layer kernels
             _FlowLogProbRevFn.overflow_fallbacks += 1
             gz, gp = _flow_log_prob_grad_fp32(zc, pc, pstride, mean_c, alpha_c, g, D, S, L, U, p_shape,
                                               ctx.needs_input_grad[0])
+        elif mode == "device":
+            # the same recomputation, enqueued now and decided on the device: every layer kernel of the pair exits at
+            # once while the flag is clear; when it is set, gated copies put its gradients in place of the poison
+            _FlowLogProbRevFn.last_overflow_flag = flag
+            check(lib.tnf_set_launch_gate(flag.data_ptr()))
+            try:
+                gz2, gp2 = _flow_log_prob_grad_fp32(zc, pc, pstride, mean_c, alpha_c, g, D, S, L, U, p_shape,
+                                                    ctx.needs_input_grad[0])
+            finally:
+                check(lib.tnf_set_launch_gate(None))
+            check(lib.tnf_gated_copy_f32(flag.data_ptr(), gp.data_ptr(), gp2.data_ptr(), gp.numel(), _lib.stream_ptr()))
+            if gz is not None:
+                check(lib.tnf_gated_copy_f32(flag.data_ptr(), gz.data_ptr(), gz2.data_ptr(), gz.numel(), _lib.stream_ptr()))
         if gz is not None and z_home != dev:
             gz = gz.to(z_home)
         return gz, (gp if p_home == dev else gp.to(p_home)), None, None, None, None, None, None
