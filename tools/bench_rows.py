@@ -6,7 +6,14 @@ import numpy as np
 import torch
 
 
+SETTLE_MS = 100.0  # back-to-back calls before timing: the GPU's clock needs ~50 ms of load to settle (bench.py `settle`)
+
+
 def timeit(fn, reps, warm=2):
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < SETTLE_MS:
+        fn()
+        torch.cuda.synchronize()
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

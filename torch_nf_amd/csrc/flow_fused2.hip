@@ -33,6 +33,9 @@
 #ifndef TNF2_RANGE_SWZ
 #define TNF2_RANGE_SWZ 1  // XOR-swizzle the staging area (conflict-free fragment reads)
 #endif
+#ifndef TNF2_STAMP
+#define TNF2_STAMP 0  // 1: diagnostic build that stamps s_memtime / s_memrealtime around the main loop (never shipped)
+#endif
 #ifndef TNF2_UNROLL
 #define TNF2_UNROLL 1  // num_stages = 4: layer loop fully unrolled (every LDS operand offset an immediate)
 #endif
@@ -273,6 +276,9 @@ flow_fused2_kernel(Flow2Args a) {
 
     f4 nlo[NT][HT], nhi[NT][HT];
     load_group(grp, nlo, nhi);
+#if TNF2_STAMP  // diagnostic build only (tools/clock_probe.py): shader clock under this kernel's own load
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (;;) {
         int nxt_off = 0;
@@ -341,6 +347,12 @@ flow_fused2_kernel(Flow2Args a) {
         if (!has_next) break;
         grp = nxt;
     }
+#if TNF2_STAMP
+    if (threadIdx.x == 0 && a.slow_count) {  // [block][cycles, 100 MHz ticks]; the buffer is nobody's output
+        a.slow_count[2 * blockIdx.x] = (unsigned)(__builtin_amdgcn_s_memtime() - st_c0);
+        a.slow_count[2 * blockIdx.x + 1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
