@@ -335,7 +335,10 @@ def main():
             opt.step()
 
         def time_train(reps=10):
-            settle(train_step, args.settle_ms)
+            # settle by COUNT here, not by wall time: with N > 1 the step contains a collective, so every rank must
+            # run the same number of them
+            for _ in range(int(args.settle_ms / 0.75) if args.settle_ms > 0 else 0):
+                train_step()
             for _ in range(2):
                 train_step()
             barrier()
