@@ -587,7 +587,10 @@ def test_hip_graph_capture(tnf, oracle):
     torch.testing.assert_close(out_static.cpu(), want, rtol=LOGP_RTOL, atol=1e-5)
 
 
-@pytest.mark.parametrize("D,S,L,M,N", [(64, 4, 2, 1, 5000), (32, 2, 3, 3, 700), (64, 1, 1, 2, 33)])
+@pytest.mark.parametrize("D,S,L,M,N", [(64, 4, 2, 1, 5000), (32, 2, 3, 3, 700), (64, 1, 1, 2, 33),
+                                       # fewer than 32 rows: partial tiles in every kernel of the chain (one parameter row;
+                                       # with several rows and N < 32 the flow composes per bijector anyway)
+                                       (64, 2, 2, 1, 2), (32, 1, 2, 1, 5), (64, 1, 2, 1, 15), (64, 4, 2, 1, 31), (32, 2, 1, 4, 31)])
 def test_batch_stats_forward_one_call_vs_per_bijector(tnf, D, S, L, M, N):
     """NormFlow.forward(freeze_bn=False) without autograd: the one-call chain (tnf_flow_forward_batch_f32: BatchNorm
     and Affine folded into the next coupling kernel, statistics over all M*N rows) against the per-bijector
