@@ -7,6 +7,10 @@
 #include "mfma_tile.h"
 #include "tnf_common.h"
 
+#ifndef TNF_LAYER_NTSTORE
+#define TNF_LAYER_NTSTORE 0
+#endif
+
 namespace tnf {
 
 // ---------------------------------------------------------------------------
@@ -366,8 +370,13 @@ coupling_mfma_kernel(MfmaLayerArgs a) {
                 float* zr = zo + row * D + 4 * q;
 #pragma unroll
                 for (int mm = 0; mm < HT; ++mm) {
+#if TNF_LAYER_NTSTORE  // around the caches: see TNF2_RANGE_NTMEM in flow_fused2.hip
+                    if (!a.skip_cond_store) __builtin_nontemporal_store(x[t][mm], reinterpret_cast<f4*>(zr + c_off + 16 * mm));
+                    __builtin_nontemporal_store(y[t][mm], reinterpret_cast<f4*>(zr + t_off + 16 * mm));
+#else
                     if (!a.skip_cond_store) *reinterpret_cast<f4*>(zr + c_off + 16 * mm) = x[t][mm];
                     *reinterpret_cast<f4*>(zr + t_off + 16 * mm) = y[t][mm];
+#endif
                 }
             }
         }

@@ -30,8 +30,17 @@
 #ifndef TNF2_RANGE_STAGE
 #define TNF2_RANGE_STAGE 1  // D = 64: rows enter and leave through an LDS staging area, 1 KB per wave instruction
 #endif
+#ifndef TNF2_RANGE_STAGE16
+#define TNF2_RANGE_STAGE16 0  // 1: stage D = 32 rows too (measured: no gain)
+#endif
 #ifndef TNF2_RANGE_SWZ
 #define TNF2_RANGE_SWZ 1  // XOR-swizzle the staging area (conflict-free fragment reads)
+#endif
+#ifndef TNF2_RANGE_NTMEM
+#define TNF2_RANGE_NTMEM 2  // bit 0: non-temporal loads, bit 1: non-temporal stores of the layer-range kernel's rows.
+                            // Measured on the 8-launch chain at D = 64: plain 0.820 ms, nt stores 0.742, nt loads 0.909,
+                            // both 1.167 -- a launch's output is the next launch's input, but 268 MB of it do not survive
+                            // in the 256 MB Infinity Cache anyway; written around it, the reads of the rows still to come stay
 #endif
 #ifndef TNF2_STAMP
 #define TNF2_STAMP 0  // 1: diagnostic build that stamps s_memtime / s_memrealtime around the main loop (never shipped)
@@ -498,7 +507,7 @@ flow_range2_kernel(Range2Args ra) {
     // (four 256-B rows) the same kernel streams at 5.1 TB/s (measured with the arithmetic removed).  So a group of
     // NT x 16 rows is loaded as it lies in memory, written to LDS as it lies (16-byte pieces XOR-swizzled by row so
     // that the fragment reads are conflict-free), read back in fragment order; results take the same way out.
-    constexpr bool STAGED = (H == 32) && TNF2_RANGE_STAGE;  // 128-B rows (D = 32) stream as fast in fragment order
+    constexpr bool STAGED = (H == 32 || TNF2_RANGE_STAGE16) && TNF2_RANGE_STAGE;  // 128-B rows (D = 32) stream as fast in fragment order
     constexpr int GF = NT * 16 * D;         // floats per group
     constexpr int NI = GF / 256;            // 1 KB wave instructions per group
     constexpr int CPR = D / 4;              // 16-byte pieces per row
@@ -518,7 +527,11 @@ flow_range2_kernel(Range2Args ra) {
                 const int off = k * 256 + lane * 4;
                 int64_t row = g * (NT * 16) + off / D;
                 if (row >= a.N) row = a.N - 1;
+#if TNF2_RANGE_NTMEM & 1
+                raw[k] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(zb + row * D + (off % D)));
+#else
                 raw[k] = *reinterpret_cast<const f4*>(zb + row * D + (off % D));
+#endif
             }
         } else {  // fragment order straight from memory: raw[(t, half, mm)]
 #pragma unroll
@@ -681,8 +694,13 @@ flow_range2_kernel(Range2Args ra) {
                     float* zr = zo + row * D + 4 * q;
 #pragma unroll
                     for (int mm = 0; mm < HT; ++mm) {
+#if TNF2_RANGE_NTMEM & 2
+                        if (st_lo) __builtin_nontemporal_store(lo[t][mm], reinterpret_cast<f4*>(zr + 16 * mm));
+                        if (st_hi) __builtin_nontemporal_store(hi[t][mm], reinterpret_cast<f4*>(zr + H + 16 * mm));
+#else
                         if (st_lo) *reinterpret_cast<f4*>(zr + 16 * mm) = lo[t][mm];
                         if (st_hi) *reinterpret_cast<f4*>(zr + H + 16 * mm) = hi[t][mm];
+#endif
                     }
                 }
             }
@@ -703,7 +721,11 @@ flow_range2_kernel(Range2Args ra) {
                     const int off = k * 256 + lane * 4;
                     const int r = off / D;
                     const f4 v = *reinterpret_cast<const f4*>(stg + sw_off(r, (off % D) >> 2));
+#if TNF2_RANGE_NTMEM & 2
+                    if (row0 + r < a.N) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(zo + (row0 + r) * D + (off % D)));
+#else
                     if (row0 + r < a.N) *reinterpret_cast<f4*>(zo + (row0 + r) * D + (off % D)) = v;
+#endif
                 }
             } else {
                 constexpr int LPR = H / 4, RPI = 64 / LPR;  // lanes per half row, half rows per instruction
@@ -712,7 +734,11 @@ flow_range2_kernel(Range2Args ra) {
                 for (int k = 0; k < NT * 16 / RPI; ++k) {
                     const int r = k * RPI + lane / LPR, ch = (hoff >> 2) + lane % LPR;
                     const f4 v = *reinterpret_cast<const f4*>(stg + sw_off(r, ch));
+#if TNF2_RANGE_NTMEM & 2
+                    if (row0 + r < a.N) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(zo + (row0 + r) * D + (ch << 2)));
+#else
                     if (row0 + r < a.N) *reinterpret_cast<f4*>(zo + (row0 + r) * D + (ch << 2)) = v;
+#endif
                 }
             }
         }
