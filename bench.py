@@ -406,8 +406,9 @@ def main():
         traffic, stamp = read_traffic("flow_range2_kernel") if D_ == 64 else (None, None)
         r = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-             "traffic_is": "HBM bytes per launch, mean over the chain's launches (PMC: 2 x FETCH_SIZE + WRITE_SIZE); it is "
-                           "BELOW the SURVEY 8(d) figure because an in-place launch stores only the half it transformed",
+             "traffic_is": "HBM bytes per dispatch of the kernel, mean over the chain's 8 streaming launches AND its one "
+                           "preparation launch (x 9/8 per streaming launch; PMC: 2 x FETCH_SIZE + WRITE_SIZE); it is BELOW "
+                           "the SURVEY 8(d) figure because an in-place launch stores only the half it transformed",
              "algorithmic_bytes_per_launch_mean": int(n * bytes_per_sample_chain(D_, k) / k),
              "algorithmic_bytes_per_sample_all_launches": bytes_per_sample_chain(D_, k)}
         if stamp is not None:

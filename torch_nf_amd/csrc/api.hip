@@ -47,14 +47,23 @@ struct FlowWs {
 static int64_t flow_image_slot(int D, int L, int U) {
     // narrow shapes: fp32 and split-f16 images share one slot size (the L = 3 fp32 image);
     // wide shapes: the wide image of exactly this (D, L, U)
-    return mfma_supported(D, L, U) ? mfma_image_floats(D, 3) : wide_image_floats(D, L, U);
+    if (!mfma_supported(D, L, U)) return wide_image_floats(D, L, U);
+    // narrow shapes: fp32 and split-f16 images share one slot size (the L = 3 fp32 image); the prepared prologues of the
+    // layer-range chain (flow_chain2_prep_floats / 2S per layer at one layer per launch, less with more) fit it too
+    const int64_t a = mfma_image_floats(D, 3);
+    return a;
+}
+static int64_t flow_prep_slot(int D, int S, int L, int U) {  // per layer, so that 2S slots hold a chain's prepared prologues
+    if (!mfma_supported(D, L, U)) return 0;
+    return (flow_chain2_prep_floats(D, S, L, 1) + 2 * S - 1) / (2 * S);
 }
 static FlowWs flow_ws(int64_t M, int64_t N, int D, int S, int L, int U) {
     FlowWs w;
     w.fold = 0;
     w.ldc = round16(M * 2 * S * 2 * D * (int64_t)sizeof(float));
     w.images = w.ldc + round16(M * (int64_t)sizeof(float));
-    w.zbuf = w.images + round16(M * 2 * S * flow_image_slot(D, L, U) * (int64_t)sizeof(float));
+    const int64_t slot = flow_image_slot(D, L, U) > flow_prep_slot(D, S, L, U) ? flow_image_slot(D, L, U) : flow_prep_slot(D, S, L, U);
+    w.zbuf = w.images + round16(M * 2 * S * slot * (int64_t)sizeof(float));
     w.ldbuf = w.zbuf + round16(M * N * D * (int64_t)sizeof(float));
     w.total = w.ldbuf + round16(M * N * (int64_t)sizeof(float));
     return w;
@@ -700,7 +709,8 @@ static int flow_log_prob_impl(const float* z, const float* params, const float* 
         float* zb = z0 ? z0 : reinterpret_cast<float*>(wsb + w.zbuf);
         float* lb = sum_log_det ? sum_log_det : reinterpret_cast<float*>(wsb + w.ldbuf);
         return launch_flow_chain2(z, zb, lb, z0, sum_log_det, log_prob, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean,
-                                  bn_alpha, interval_consts, exact_reruns, g_layer_variant >= 11 ? g_layer_variant - 10 : 1, st);
+                                  bn_alpha, interval_consts, exact_reruns, g_layer_variant >= 11 ? g_layer_variant - 10 : 1, st,
+                                  0, images);  // `images`: the workspace region that holds the prepared prologues
     }
     // fp32-MFMA per-layer chain on the narrow shapes: in place from the second kernel on, each kernel storing only the
     // half it transforms (the folds are composed accordingly, flow_fold_kernel chain = 1)

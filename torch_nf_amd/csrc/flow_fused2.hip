@@ -377,7 +377,23 @@ struct Range2Args {
     int c_hi, c_lo;       // layer range, 2S-1 >= c_hi >= c_lo >= 0
     const float* ld_in;   // running log-det of the launches before (M, N), or NULL
     int store_cond;       // non-final launches: also store the conditioner half of layer c_lo (before its fold)
+    // Prepared prologues.  Every launch of a chain spends ~8 us folding constants and building its layers' operand images
+    // before it touches a sample -- 8 % of a 2^20-sample launch, with the memory system idle.  So the chain runs ONE
+    // preparation launch first (prep_out != NULL, grid.x = number of launches: workgroup x does the prologue of launch x
+    // and dumps the LDS region [images .. support constants] to prep_out), and the streaming launches (prep != NULL) just
+    // copy their region back.  per_launch: layers per launch of the chain (the preparation launch derives its ranges
+    // from it); slot: floats between the regions of consecutive launches.
+    const float* prep;
+    float* prep_out;
+    int per_launch;
+    int64_t prep_slot;
 };
+
+// floats of the LDS region a prepared prologue consists of (everything behind the staging area)
+template <int H, int L>
+__host__ __device__ constexpr int range2_region_floats(int nr) {
+    return nr * Img2<H, L>::FLOATS + (nr + 1) * 4 * H + 2 * H + ((nr + 3) / 4) * 4 + 4 + 16 + 7 * 2 * H;
+}
 
 template <int H, int L>
 __host__ __device__ constexpr int range2_lds_floats(int nr) {
@@ -414,7 +430,12 @@ flow_range2_kernel(Range2Args ra) {
     const Flow2Args& a = ra.f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nl = 2 * a.S;
-    const int c_hi = ra.c_hi, c_lo = ra.c_lo, nr = c_hi - c_lo + 1;
+    int c_hi_ = ra.c_hi, c_lo_ = ra.c_lo;
+    if (ra.prep_out) {  // preparation launch: workgroup x stands in for launch x of the chain
+        c_hi_ = nl - 1 - (int)blockIdx.x * ra.per_launch;
+        c_lo_ = c_hi_ - ra.per_launch + 1 > 0 ? c_hi_ - ra.per_launch + 1 : 0;
+    }
+    const int c_hi = c_hi_, c_lo = c_lo_, nr = c_hi - c_lo + 1;
     const int c_top = c_hi < nl - 1 ? c_hi + 1 : c_hi;  // folds are needed for c_lo .. c_top
     const bool final_ = c_lo == 0;
     float* stage = lds;                                // [NWAVES][NT * 16 rows][D]: wave-private staging of the rows in flight
@@ -434,7 +455,16 @@ flow_range2_kernel(Range2Args ra) {
     const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
     const float* prow = a.params + mp * a.pstride;
     const bool has_iv = a.iv != nullptr && c_hi == nl - 1;
+    const int launch_ix = (nl - 1 - c_hi) / (ra.per_launch > 0 ? ra.per_launch : 1);
+    const int nlaunch = ra.per_launch > 0 ? (nl + ra.per_launch - 1) / ra.per_launch : 1;
+    const int region = range2_region_floats<H, L>(nr);  // img .. ivc, contiguous
 
+    if (ra.prep) {  // prepared prologue: copy the region back
+        const f4* src = reinterpret_cast<const f4*>(ra.prep + ((int64_t)mp * nlaunch + launch_ix) * ra.prep_slot);
+        f4* dst = reinterpret_cast<f4*>(img);
+        for (int i = threadIdx.x; i < region / 4; i += NWAVES * 64) dst[i] = src[i];
+        __syncthreads();
+    } else {
     {   // prologue A: folds of the range (+ the one owed from the launch before); the constant log-det on the last launch
         for (int i = threadIdx.x; i < (c_top - c_lo + 1) * D; i += NWAVES * 64) {
             const int ci = i / D, d = i - ci * D;
@@ -482,6 +512,13 @@ flow_range2_kernel(Range2Args ra) {
         }
     }
     __syncthreads();
+    }  // in-kernel prologue
+    if (ra.prep_out) {  // preparation launch: hand the region over and leave
+        f4* dst = reinterpret_cast<f4*>(ra.prep_out + ((int64_t)mp * nlaunch + launch_ix) * ra.prep_slot);
+        const f4* src = reinterpret_cast<const f4*>(img);
+        for (int i = threadIdx.x; i < region / 4; i += NWAVES * 64) dst[i] = src[i];
+        return;
+    }
 
     const float presc = pow2i(-kap[c_hi - c_lo]);
     const float unsc = pow2i(kap[0]);
@@ -821,6 +858,27 @@ static int launch_range_t(const Range2Args& ra, int64_t M, hipStream_t st) {
     return TNF_OK;
 }
 
+// the preparation launch of a chain (Range2Args::prep_out): one workgroup per (launch of the chain, context)
+template <int H, int L, int PREC>
+static int launch_range_prep_t(const Range2Args& ra, int64_t Mp, int nlaunch, hipStream_t st) {
+    constexpr int NT = TNF2_RANGE_NT, NW = TNF2_RANGE_NW;
+    const size_t smem = (size_t)range2_lds_floats<H, L>(ra.per_launch) * sizeof(float);
+    auto kern = flow_range2_kernel<H, L, NT, NW, false, false, PREC>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return fail(TNF_ELAUNCH, "flow_range2 (preparation): cannot reserve %zu B of LDS", smem);
+    hipLaunchKernelGGL(kern, grid_xm(nlaunch, Mp), dim3(NW * 64), smem, st, ra);
+    return TNF_OK;
+}
+
+int64_t flow_chain2_prep_floats(int D, int S, int L, int per_launch) {
+    // per context: one region per launch, each at the stride of a full range
+    if (per_launch < 1) per_launch = 1;
+    const int nlaunch = (2 * S + per_launch - 1) / per_launch;
+    const int64_t slot = (D == 64) ? (L == 1 ? range2_region_floats<32, 1>(per_launch) : (L == 2 ? range2_region_floats<32, 2>(per_launch) : range2_region_floats<32, 3>(per_launch)))
+                                   : (L == 1 ? range2_region_floats<16, 1>(per_launch) : (L == 2 ? range2_region_floats<16, 2>(per_launch) : range2_region_floats<16, 3>(per_launch)));
+    return nlaunch * slot;
+}
+
 bool flow_range2_supported(int D, int L, int U, int nlayers) {
     if (!mfma_supported(D, L, U) || nlayers < 1) return false;
     const size_t b = (D == 64) ? (L == 1 ? range2_lds_floats<32, 1>(nlayers) : (L == 2 ? range2_lds_floats<32, 2>(nlayers) : range2_lds_floats<32, 3>(nlayers)))
@@ -833,7 +891,7 @@ bool flow_range2_supported(int D, int L, int U, int nlayers) {
 int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, float* sum_log_det, float* log_prob, int64_t Mz,
                        int64_t Mp, int64_t N, int D, int S, int L, int U, const float* params, int64_t pstride,
                        const float* bn_mean, const float* bn_alpha, const float* interval_consts, unsigned* slow_count,
-                       int per_launch, hipStream_t st, int prec) {
+                       int per_launch, hipStream_t st, int prec, float* prep_ws) {
     const int nl = 2 * S;
     if (per_launch < 1) per_launch = 1;
     if (!flow_range2_supported(D, L, U, per_launch))
@@ -841,6 +899,31 @@ int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, flo
     if (N <= 0) return TNF_OK;
     const int64_t M = Mz > Mp ? Mz : Mp;
     const FlowLayout fl = flow_layout(D, S, L, U);
+    const int nlaunch = (nl + per_launch - 1) / per_launch;
+    const int64_t prep_slot = flow_chain2_prep_floats(D, S, L, per_launch) / nlaunch;
+    if (nlaunch < 2) prep_ws = nullptr;  // one launch: its own prologue is the preparation
+    if (prep_ws) {  // every launch's prologue in one small launch up front (Range2Args::prep)
+        Range2Args ra;
+        ra.f = Flow2Args{z, nullptr, nullptr, nullptr, Mp, Mp, N, S, U, params, bn_mean, bn_alpha, pstride, fl.stage,
+                         fl.p_up + fl.p_low, fl.p_up, interval_consts, nullptr};
+        ra.c_hi = nl - 1;
+        ra.c_lo = nl - per_launch > 0 ? nl - per_launch : 0;
+        ra.ld_in = nullptr;
+        ra.store_cond = 0;
+        ra.prep = nullptr;
+        ra.prep_out = prep_ws;
+        ra.per_launch = per_launch;
+        ra.prep_slot = prep_slot;
+        int rc;
+#define TNF_PREP(HH, LL) rc = prec == 1 ? launch_range_prep_t<HH, LL, 1>(ra, Mp, nlaunch, st) : launch_range_prep_t<HH, LL, 0>(ra, Mp, nlaunch, st)
+        if (D == 64) {
+            if (L == 1) TNF_PREP(32, 1); else if (L == 2) TNF_PREP(32, 2); else TNF_PREP(32, 3);
+        } else {
+            if (L == 1) TNF_PREP(16, 1); else if (L == 2) TNF_PREP(16, 2); else TNF_PREP(16, 3);
+        }
+#undef TNF_PREP
+        if (rc != TNF_OK) return rc;
+    }
     for (int c_hi = nl - 1; c_hi >= 0; c_hi -= per_launch) {
         const int c_lo = c_hi - per_launch + 1 > 0 ? c_hi - per_launch + 1 : 0;
         const bool first = c_hi == nl - 1, last = c_lo == 0;
@@ -854,6 +937,10 @@ int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, flo
         // the conditioner half of the range's last layer must be written unless it is in zbuf already: a later launch of
         // ONE layer did not touch it (with more layers per launch the layer before transformed it inside the launch)
         ra.store_cond = (first || c_hi > c_lo) ? 1 : 0;
+        ra.prep = prep_ws;
+        ra.prep_out = nullptr;
+        ra.per_launch = per_launch;
+        ra.prep_slot = prep_slot;
         int rc;
 #define TNF_RANGE(HH, LL) rc = prec == 1 ? launch_range_t<HH, LL, 1>(ra, M, st) : launch_range_t<HH, LL, 0>(ra, M, st)
         if (D == 64) {
