@@ -36,6 +36,7 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
 --no-extras skips train_step, configs and widened (a clean per-kernel average under rocprofv3 --stats).
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -275,11 +276,18 @@ def main():
     def run(model, zz, fusion, steps, warmup, settle_ms=None):
         model.fusion = fusion
         with torch.no_grad():
+            # events first: HIP creates an event at its first record, and now and then that costs the host tens of ms --
+            # neither inside the timed region nor between the settle phase and it (an idle GPU drops its clock again)
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                     for _ in range(steps)]
+            for a, b in pairs:
+                a.record()
+                b.record()
+            gc.collect()
+            gc.disable()
             settle(lambda: model.log_prob(zz), args.settle_ms if settle_ms is None else settle_ms)
             for _ in range(warmup):
                 model.log_prob(zz)
-            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                     for _ in range(steps)]
             barrier()
             t0 = time.perf_counter()
             for a, b in pairs:
@@ -288,6 +296,7 @@ def main():
                 b.record()
             barrier()
             wall = time.perf_counter() - t0
+            gc.enable()
         model.fusion = L_.FUSE_AUTO
         return wall, [a.elapsed_time(b) for a, b in pairs], out
 

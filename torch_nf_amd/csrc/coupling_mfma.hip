@@ -55,7 +55,9 @@ __device__ __forceinline__ void fold_consts(const float* __restrict__ p, const f
 __global__ void __launch_bounds__(256)
 flow_fold_kernel(const float* __restrict__ params, const float* __restrict__ bn_mean,
                  const float* __restrict__ bn_alpha, float* __restrict__ fold,
-                 float* __restrict__ ldc, int D, int S, int L, int U, int64_t pstride, int inverse, int chain) {
+                 float* __restrict__ ldc, int D, int S, int L, int U, int64_t pstride, int inverse, int chain,
+                 const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;  // a conditionally needed launch (tnf_set_launch_gate): nothing to do
     __shared__ float red[256];
     const int m = blockIdx.x;
     const float* p = params + (int64_t)m * pstride;
@@ -98,7 +100,8 @@ __global__ void __launch_bounds__(256)
 flow_fold_backward_kernel(const float* __restrict__ params, const float* __restrict__ bn_alpha,
                           const float* __restrict__ g_fold, const float* __restrict__ glp_sum,
                           float* __restrict__ g_params, int D, int S, int L, int U, int64_t pstride,
-                          int64_t gpstride) {
+                          int64_t gpstride, const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;  // a conditionally needed launch (tnf_set_launch_gate): nothing to do
     const int64_t mp = blockIdx.x;
     const float sum_glp = glp_sum[mp];  // sum of g_log_prob over the samples that use this row
     const FlowLayout fl = flow_layout(D, S, L, U);
@@ -121,7 +124,7 @@ int launch_flow_fold_backward(const float* params, const float* bn_alpha, const 
                               float* g_params, int64_t Mp, int D, int S, int L, int U, int64_t pstride,
                               int64_t gpstride, hipStream_t st) {
     hipLaunchKernelGGL(flow_fold_backward_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_alpha, g_fold,
-                       glp_sum, g_params, D, S, L, U, pstride, gpstride);
+                       glp_sum, g_params, D, S, L, U, pstride, gpstride, g_launch_gate);
     return check_launch("flow_fold_backward");
 }
 
@@ -135,7 +138,8 @@ int launch_flow_fold_backward(const float* params, const float* bn_alpha, const 
 template <int H, int L>
 __global__ void __launch_bounds__(64)
 flow_images_kernel(const float* __restrict__ params, float* __restrict__ images, int S, int U,
-                   int64_t pstride, int64_t image_floats, int64_t Mp) {
+                   int64_t pstride, int64_t image_floats, int64_t Mp, const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;  // a conditionally needed launch (tnf_set_launch_gate): nothing to do
     constexpr int D = 2 * H;
     const int c = blockIdx.x;
     const int64_t m = grid_m();
@@ -157,7 +161,7 @@ int launch_flow_images(const float* params, float* images, int64_t Mp, int D, in
     const dim3 grid = grid_xm(2 * S, Mp);
     const int64_t fl = mfma_image_floats(D, L);
 #define TNF_IMG(HH, LL) \
-    hipLaunchKernelGGL((flow_images_kernel<HH, LL>), grid, dim3(64), 0, st, params, images, S, U, pstride, fl, Mp)
+    hipLaunchKernelGGL((flow_images_kernel<HH, LL>), grid, dim3(64), 0, st, params, images, S, U, pstride, fl, Mp, g_launch_gate)
     if (D == 64) {
         if (L == 1) TNF_IMG(32, 1); else if (L == 2) TNF_IMG(32, 2); else TNF_IMG(32, 3);
     } else {
@@ -171,7 +175,7 @@ int launch_flow_prep(const float* params, const float* bn_mean, const float* bn_
                      float* ldc, float* images, int64_t Mp, int D, int S, int L, int U,
                      int64_t pstride, int inverse, hipStream_t st, int chain) {
     hipLaunchKernelGGL(flow_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, bn_mean,
-                       bn_alpha, fold, ldc, D, S, L, U, pstride, inverse, chain);
+                       bn_alpha, fold, ldc, D, S, L, U, pstride, inverse, chain, g_launch_gate);
     if (!images) return check_launch("flow_prep");  // wide shapes build their own images
     return launch_flow_images(params, images, Mp, D, S, L, U, pstride, st);
 }

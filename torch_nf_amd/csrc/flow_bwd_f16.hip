@@ -170,7 +170,8 @@ flow_rev_images_kernel(const float* __restrict__ params, const float* __restrict
 }
 
 __global__ void __launch_bounds__(256)
-flow_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ out) {
+flow_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ out, const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;  // a conditionally needed launch (tnf_set_launch_gate): nothing to do
     __shared__ float red[4];
     float m = 0.f;
     const int64_t n4 = (reinterpret_cast<uintptr_t>(g) & 15) == 0 ? n >> 2 : 0;  // 16-byte part, four loads in flight
@@ -198,7 +199,7 @@ int launch_gmax(const float* g, int64_t n, unsigned* out, hipStream_t st) {
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, out);
+    hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, out, g_launch_gate);
     return check_launch("gmax");
 }
 
@@ -1228,7 +1229,7 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
         const int64_t n = M * N;
         int64_t blocks = (n + 255) / 256;
         if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_lp, n, gmax);
+        hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_lp, n, gmax, (const int*)nullptr);
     }
     const FlowLayout fl = flow_layout(D, S, L, U);
     const size_t smem = (size_t)rev_lds_bytes(D, S, L, U);
