@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import torch_nf_amd as tnf  # noqa: E402
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300  # >= 200: an idle GPU needs ~50 ms of load to reach its clock
 S, L, U, N = 4, 2, 15, 1 << 20
 rng = np.random.RandomState(0)
 nf = tnf.NormFlow(D, False, "coupling", S, L, U)
@@ -33,7 +33,7 @@ want = None
 for name, fusion in (("flow ", tnf._lib.FUSE_FLOW), ("layer", tnf._lib.FUSE_LAYER)):
     nf.fusion = fusion
     with torch.no_grad():
-        for _ in range(3):
+        for _ in range(3 if steps < 100 else 250):  # short runs: cold clocks on purpose (PMC passes); long runs: settled
             lp = nf.log_prob(z)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         for a, b in ev:
