@@ -42,6 +42,9 @@
                             // both 1.167 -- a launch's output is the next launch's input, but 268 MB of it do not survive
                             // in the 256 MB Infinity Cache anyway; written around it, the reads of the rows still to come stay
 #endif
+#ifndef TNF2_FUSED_STAGE
+#define TNF2_FUSED_STAGE 1  // whole-flow kernel: row outputs through LDS staging tiles + non-temporal stores
+#endif
 #ifndef TNF2_STAMP
 #define TNF2_STAMP 0  // 1: diagnostic build that stamps s_memtime / s_memrealtime around the main loop (never shipped)
 #endif
@@ -109,6 +112,7 @@ flow_fused2_kernel(Flow2Args a) {
     int* qhead = kap + ((nl + 3) / 4) * 4;
     float* red = reinterpret_cast<float*>(qhead + 4);  // [16] partial log-det constants
     float* ivc = red + 16;                             // [7][D]
+    float* stage = ivc + 7 * D;                        // [NWAVES][16 rows][D], only when a.stage_out (the launcher sized it)
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -344,12 +348,33 @@ flow_fused2_kernel(Flow2Args a) {
                 if (q == 0 && row_ok) lpo[row] = -0.5f * sq - (float)D * 0.91893853320467274178f - ld_tot;
             }
             if (sldo && q == 0 && row_ok) sldo[row] = ld_tot;
-            if (zo && row_ok) {
+            if (zo && !a.stage_out && row_ok) {
                 float* zr = zo + row * D + 4 * q;
 #pragma unroll
                 for (int mm = 0; mm < HT; ++mm) {
                     *reinterpret_cast<f4*>(zr + 16 * mm) = lo[t][mm];
                     *reinterpret_cast<f4*>(zr + H + 16 * mm) = hi[t][mm];
+                }
+            }
+            if (zo && a.stage_out) {
+                // rows leave through a wave-private swizzled staging tile, 1 KB (whole 128-B lines) per instruction and
+                // around the caches: straight from the fragment layout (64 B per lane group) the stores cost the kernel
+                // 0.036 ms at D = 64 (0.227 -> 0.263), this way ... (the layer-range kernel's recipe, below)
+                constexpr int CPR = D / 4, RPB = (64 / CPR) > 0 ? (64 / CPR) : 1;
+                float* stg = stage + wave * 16 * D;
+                auto sw = [&](int r, int ch) -> int { return r * D + ((ch ^ ((r / RPB) & (CPR - 1))) << 2); };
+#pragma unroll
+                for (int mm = 0; mm < HT; ++mm) {
+                    *reinterpret_cast<f4*>(stg + sw(s, 4 * mm + q)) = lo[t][mm];
+                    *reinterpret_cast<f4*>(stg + sw(s, H / 4 + 4 * mm + q)) = hi[t][mm];
+                }
+                const int64_t row0 = (grp * NT + t) * 16;
+#pragma unroll
+                for (int k = 0; k < 16 * D / 256; ++k) {
+                    const int off = k * 256 + lane * 4;
+                    const int r = off / D;
+                    const f4 v = *reinterpret_cast<const f4*>(stg + sw(r, (off % D) >> 2));
+                    if (row0 + r < a.N) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(zo + (row0 + r) * D + (off % D)));
                 }
             }
         }
@@ -801,7 +826,12 @@ bool flow_fused2_supported(int D, int S, int L, int U) {
 
 template <int H, int L, int NT, int NW, int SS, bool FWD>
 static int launch2_t(const Flow2Args& a, int64_t M, hipStream_t st) {
-    const size_t smem = flow2_lds_bytes<H, L>(a.S);
+    size_t smem = flow2_lds_bytes<H, L>(a.S);
+    Flow2Args b = a;
+    // row output (z0 / z): through the staging tiles when they fit beside the operand images (D = 64 only: 128-B rows gain nothing)
+    const size_t stage_bytes = (size_t)NW * 16 * 2 * H * sizeof(float);
+    b.stage_out = (H == 32 && a.z_out != nullptr && smem + stage_bytes <= 160 * 1024 && TNF2_FUSED_STAGE) ? 1 : 0;
+    if (b.stage_out) smem += stage_bytes;
     auto kern = flow_fused2_kernel<H, L, NT, NW, SS, FWD>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_fused2: cannot reserve %zu B of LDS", smem);
@@ -809,7 +839,7 @@ static int launch2_t(const Flow2Args& a, int64_t M, hipStream_t st) {
     int64_t bx = (ngroups + NW - 1) / NW;
     int64_t cap = (256 + M - 1) / M;  // one workgroup per CU (LDS-limited), persistent over its groups
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(NW * 64), smem, st, a);
+    hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(NW * 64), smem, st, b);
     return TNF_OK;
 }
 

@@ -142,6 +142,7 @@ struct Flow2Args {
     int64_t pstride, stage_stride, affine_off, low_off;
     const float* iv;     // (7, D) constants of a fused ToInterval support layer, or NULL
     unsigned* slow_count;  // optional: += number of groups re-run through the exact path (testing / diagnostics)
+    int stage_out;         // set by the launcher: row outputs leave through LDS staging tiles (flow_fused2.hip)
 };
 
 bool flow_fused2_supported(int D, int S, int L, int U);
