@@ -486,6 +486,52 @@ flow_batch_fold_kernel(const float* __restrict__ params, int64_t pstride, int64_
     if (threadIdx.x == 0) ldc[m] = (first ? 0.f : ldc[m]) + red[0] + *ld_bn;
 }
 
+// The same with the BatchNorm finalisation in front (bn_finalize_kernel's arithmetic): mean / alpha of the layer's batch
+// statistics from moments = [sum (D) | sum of squares (D) | row count] doubles -- every workgroup derives them itself
+// (D values), workgroup 0 hands them out.  One launch instead of two on a chain whose small kernels are launch-bound.
+// (Tried and dropped: the statistics as per-wave column sums inside the coupling kernel.  Its 182 VGPRs + 64 AGPRs leave
+// no room for accumulators at two waves per SIMD: with doubles the kernel falls to one wave (103 us instead of 55), with
+// floats and one tile per wave it takes 71 us, and reducing 8,192 partial rows costs more than the 31 us pass it saves.)
+__global__ void __launch_bounds__(256)
+flow_batch_finalize_fold_kernel(const float* __restrict__ params, int64_t pstride, int64_t affine_off,
+                                const double* __restrict__ moments, float eps, float* __restrict__ mean_out,
+                                float* __restrict__ alpha_out, float* __restrict__ fold, float* __restrict__ ldc, int D,
+                                int has_affine, int first) {
+    const int64_t m = blockIdx.x;
+    const float* ap = params + m * pstride + affine_off;
+    const double rows = moments[2 * D];
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const double mud = moments[d] / rows;
+        double var_b = moments[D + d] / rows - mud * mud;
+        if (var_b < 0.0) var_b = 0.0;
+        const double ad = sqrt(var_b + (double)eps);
+        const float mu = (float)mud, rs = (float)(1.0 / ad);
+        if (m == 0) {
+            mean_out[d] = mu;
+            alpha_out[d] = (float)ad;
+        }
+        acc -= logf((float)ad);  // BatchNorm's log-det
+        float A = rs, B = -mu * rs;
+        if (has_affine) {
+            const float av = ap[d], ea = expf(av);
+            acc += av;
+            A = ea * rs;
+            B = ap[D + d] - mu * A;
+        }
+        fold[m * 2 * D + d] = A;
+        fold[m * 2 * D + D + d] = B;
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ldc[m] = (first ? 0.f : ldc[m]) + red[0];
+}
+
 // z_out <- z A[m] + B[m] (z_out may be z), sum_log_det[m][n] += ldc[m]
 __global__ void __launch_bounds__(256)
 flow_fold_apply_kernel(const float* z, float* z_out, float* __restrict__ sld, const float* __restrict__ fold,
@@ -591,12 +637,9 @@ int flow_forward_batch_fold(int c, const float* params, const double* moments, f
     const FbWs w = fb_ws(ws, Mp, D);
     const FlowLayout fl = flow_layout(D, S, L, U);
     if (!moments) moments = w.moments;
-    int rc = launch_bn_finalize(moments, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D, w.rstd, w.ld_bn, D, eps,
-                                st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(flow_batch_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
-                       (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, bn_mean_out + (int64_t)c * D, w.rstd, w.ld_bn,
-                       w.fold, w.ldc, D, c & 1, c == 0);
+    hipLaunchKernelGGL(flow_batch_finalize_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
+                       (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, moments, eps, bn_mean_out + (int64_t)c * D,
+                       bn_alpha_out + (int64_t)c * D, w.fold, w.ldc, D, c & 1, c == 0);
     return check_launch("flow_forward_batch_fold");
 }
 
@@ -787,7 +830,7 @@ int launch_flow_forward_train_fwd(const float* omega, const float* params, float
     if (!mfma_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "flow_forward_train: D=%d L=%d U=%d", D, L, U);
     if (N <= 0) return TNF_OK;
     const FbWs w = fb_ws(ws, Mp, D);
-    float *ldc = w.ldc, *rstd = w.rstd, *ld_bn = w.ld_bn, *images = w.images;
+    float *ldc = w.ldc, *images = w.images;
     double* sums = w.moments;
     const FlowLayout fl = flow_layout(D, S, L, U);
     const int nl = 2 * S;
@@ -813,11 +856,9 @@ int launch_flow_forward_train_fwd(const float* omega, const float* params, float
         if (rc) return rc;
         rc = launch_bn_moments(states + (int64_t)c * plane, sums, M * N, D, st);
         if (rc) return rc;
-        rc = launch_bn_finalize(sums, bn_mean_out + (int64_t)c * D, bn_alpha_out + (int64_t)c * D, rstd, ld_bn, D, eps, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(flow_batch_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
-                           (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, bn_mean_out + (int64_t)c * D, rstd, ld_bn,
-                           folds + (int64_t)c * Mp * 2 * D, ldc, D, c & 1, c == 0);
+        hipLaunchKernelGGL(flow_batch_finalize_fold_kernel, dim3((unsigned)Mp), dim3(256), 0, st, params, pstride,
+                           (int64_t)(c >> 1) * fl.stage + fl.p_up + fl.p_low, sums, eps, bn_mean_out + (int64_t)c * D,
+                           bn_alpha_out + (int64_t)c * D, folds + (int64_t)c * Mp * 2 * D, ldc, D, c & 1, c == 0);
     }
     int64_t nb = (N * D / 4 + 255) / 256;
     if (nb > 2048) nb = 2048;

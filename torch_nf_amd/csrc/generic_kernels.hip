@@ -296,7 +296,7 @@ bn_stats_kernel(const float* __restrict__ z, double* __restrict__ sums, int64_t 
 // (64 values) folded into double accumulators -- same sums as bn_stats_kernel to ~1e-7 relative.
 __global__ void __launch_bounds__(256)
 bn_stats_vec_kernel(const float* __restrict__ z, double* __restrict__ sums, int64_t rows, int D,
-                    int64_t rows_per_block) {
+                    int64_t rows_per_block, int write_count) {
     extern __shared__ double red[];  // [rpi][2][D]
     const int tid = threadIdx.x;
     const int lanes = D >> 2;            // threads per row
@@ -342,6 +342,7 @@ bn_stats_vec_kernel(const float* __restrict__ z, double* __restrict__ sums, int6
         for (int rr = 0; rr < rpi; ++rr) a += red[rr * 2 * D + d];
         atomicAdd(&sums[d], a);
     }
+    if (write_count && blockIdx.x == 0 && tid == 0) sums[2 * D] = (double)rows;  // moments = [sums | sums of squares | count]
 }
 
 __global__ void __launch_bounds__(256)
@@ -382,7 +383,9 @@ bn_normalize_kernel(const float* __restrict__ z, const float* __restrict__ mean,
     }
 }
 
-static void launch_bn_sums(const float* z, double* sums, int64_t rows, int D, int64_t blocks, int64_t rpb, hipStream_t st) {
+// returns true when the kernel also wrote the row count behind the sums (write_count asked for and the vector kernel ran)
+static bool launch_bn_sums(const float* z, double* sums, int64_t rows, int D, int64_t blocks, int64_t rpb, hipStream_t st,
+                           int write_count = 0) {
     const bool vec = (D % 4) == 0 && D <= 1024 && (reinterpret_cast<uintptr_t>(z) & 15) == 0;
     if (vec) {
         const int rpi = 256 / (D / 4);
@@ -393,10 +396,11 @@ static void launch_bn_sums(const float* z, double* sums, int64_t rows, int D, in
         if (blocks < 1) blocks = 1;
         rpb = (rows + blocks - 1) / blocks;
         hipLaunchKernelGGL(bn_stats_vec_kernel, dim3((unsigned)blocks), dim3(256), (size_t)rpi * 2 * D * sizeof(double), st, z,
-                           sums, rows, D, rpb);
-    } else {
-        hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, sums, rows, D, rpb);
+                           sums, rows, D, rpb, write_count);
+        return write_count != 0;
     }
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, sums, rows, D, rpb);
+    return false;
 }
 
 // local moments of z (rows, D) for a batch-statistics BatchNorm whose normalisation is folded into the next kernel by
@@ -404,15 +408,16 @@ static void launch_bn_sums(const float* z, double* sums, int64_t rows, int D, in
 __global__ void bn_count_kernel(double* __restrict__ moments, int D, double rows) { moments[2 * D] = rows; }
 
 int launch_bn_moments(const float* z, double* moments, int64_t rows, int D, hipStream_t st) {
-    if (hipMemsetAsync(moments, 0, sizeof(double) * 2 * (size_t)D, st) != hipSuccess)
+    if (hipMemsetAsync(moments, 0, sizeof(double) * (2 * (size_t)D + 1), st) != hipSuccess)  // an empty shard: count 0
         return fail(TNF_ELAUNCH, "bn_moments: memset failed");
-    hipLaunchKernelGGL(bn_count_kernel, dim3(1), dim3(1), 0, st, moments, D, (double)rows);
+    bool counted = rows <= 0;
     if (rows > 0) {
         int64_t blocks = (rows + 255) / 256;
         if (blocks > 1024) blocks = 1024;
         const int64_t rpb = (rows + blocks - 1) / blocks;
-        launch_bn_sums(z, moments, rows, D, blocks, rpb, st);
+        counted = launch_bn_sums(z, moments, rows, D, blocks, rpb, st, 1);
     }
+    if (!counted) hipLaunchKernelGGL(bn_count_kernel, dim3(1), dim3(1), 0, st, moments, D, (double)rows);
     return check_launch("bn_moments");
 }
 
