@@ -1,4 +1,5 @@
-"""Emulate the 3-MFMA f16-split coupling MLP in numpy and compare log_prob with the oracle."""
+"""Analysis script (not collected by pytest; lives under tests/ because it imports the oracle): emulate the 3-MFMA
+f16-split coupling MLP in numpy and compare log_prob with the oracle.  Run from the repo root: python tests/split_f16_emulation.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
 import flow_oracle as orc
