@@ -474,6 +474,43 @@ def test_flow_reversible_backward_overflow_falls_back(tnf, oracle):
         assert bool(torch.isnan(gp).any()) == bool(want_flag), (want_flag, int(torch.isnan(gp).sum()), gp.numel())
 
 
+def test_overflow_recovery_inside_a_hip_graph(tnf, oracle):
+    """The device-gated recovery needs no host round trip, so a training step captured as ONE HIP graph
+    (graphs.GraphedStep) recovers too: the captured step is replayed on a batch whose gradient terms leave the
+    fixed-point budget, and the parameter gradient equals torch autograd over the oracle (a captured "host"-mode step
+    cannot read the flag and would return the NaN poison)."""
+    D, S, L, U, N = 64, 4, 2, 15, 4096
+    rng = np.random.RandomState(2)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.05, (1, nf.D_params))).float()
+    stats = [(torch.zeros(D), torch.ones(D))] * (2 * S)
+    z_ok = torch.tensor(rng.normal(0, 1, (1, N, D))).float()
+    z_bad = z_ok.clone()
+    z_bad[0, ::512] *= 3000.0
+    p_ref = p0.clone().requires_grad_()
+    (-oracle.flow_log_prob(z_bad, p_ref, D, S, L, U, stats).sum()).backward()
+    p = p0.cuda().requires_grad_()
+    z = z_ok.cuda().clone()  # the captured step reads this buffer: its contents change between replays
+    grad_out = torch.zeros_like(p)
+
+    def step():
+        p.grad = None
+        (-nf.log_prob(z, p).sum()).backward()
+        grad_out.copy_(p.grad)
+        return grad_out
+
+    assert tnf.ops._FlowLogProbRevFn.overflow_recovery == "device"
+    gs = tnf.graphs.GraphedStep(step, warmup=2)
+    g_ok = gs().clone()
+    assert bool(torch.isfinite(g_ok).all())
+    z.copy_(z_bad.cuda())
+    g_bad = gs().clone()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g_bad).all()), "the captured step must have recovered on the device"
+    scale = float(p_ref.grad.abs().max())
+    torch.testing.assert_close(g_bad.cpu() / scale, p_ref.grad / scale, rtol=2e-3, atol=2e-5)
+
+
 @pytest.mark.parametrize("arch,D,S", [("coupling", 64, 2), ("coupling", 6, 1), ("AR", 6, 1)])
 def test_bn_statistics_stay_in_graph(tnf, oracle, arch, D, S):
     """The reference caches last_mean / last_alpha WITHOUT detach (bijectors.py:414-415): `nf(N)` followed by
