@@ -468,6 +468,16 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
                          int32_t num_units, int64_t params_row_stride, int32_t fusion,
                          void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same plus the log-density NormFlow.forward returns beside the samples (density_estimator.py:369-372, 387):
+ * log_q[m][n] = log N(omega[m][n]; 0, I) - sum_log_det[m][n], float64 (the base density summed in float64 from the
+ * float32 draw), written by the whole-flow kernel itself -- no separate pass over omega.  TNF_EUNSUPPORTED unless the
+ * default whole-flow kernel runs the call (fusion AUTO / FLOW, tnf_flow_fused_supported shapes). */
+int tnf_flow_forward_logq_f32(const float* omega, const float* params, const float* bn_mean, const float* bn_alpha,
+                              const float* interval_consts, float* z_out, float* sum_log_det, double* log_q, int64_t M_z,
+                              int64_t M_p, int64_t N, int32_t D, int32_t num_stages, int32_t num_layers,
+                              int32_t num_units, int64_t params_row_stride, int32_t fusion, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -567,6 +567,34 @@ def test_sample_uses_device_rng_and_matches_log_prob(tnf):
         assert torch.equal(z, z2)  # same generator state -> same draw, same kernels -> same bits
 
 
+def test_forward_log_q_from_the_sampling_kernel(tnf):
+    """tnf_flow_forward_logq_f32: the whole-flow sampling kernel writes log_q = log N(omega; 0, I) - sum_log_det itself
+    (density_estimator.py:369-372, 387) -- the same float64 value as the separate base-density kernel minus the kernel's
+    own float32 log-det, with per-context rows and with a ToInterval support layer; variants without that output say so
+    (None) and NormFlow falls back to the separate kernel."""
+    ops, L_ = tnf.ops, tnf._lib
+    D, S, L, U = 64, 4, 2, 15
+    for M, N in ((1, 5000), (3, 77)):
+        nf, params, stats = _rand_flow(tnf, D, S, L, U, seed=50 + M, M=M)
+        _install_stats(nf, [m.numpy() for m, _ in stats], [a.numpy() for _, a in stats])
+        mean, alpha = nf._bn_stats(torch.device("cuda"))
+        om = torch.randn(M, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(M))
+        with torch.no_grad():
+            z, sld, lq = ops.flow_forward_raw(om, params.cuda(), mean, alpha, D, S, L, U, L_.FUSE_FLOW, want_log_q=True)
+            z2, sld2 = ops.flow_forward_raw(om, params.cuda(), mean, alpha, D, S, L, U, L_.FUSE_FLOW)
+            want = ops.base_log_density_f64(om) - sld2
+        assert lq is not None and lq.dtype == torch.float64
+        assert torch.equal(z, z2) and torch.equal(sld, sld2)
+        torch.testing.assert_close(lq, want, rtol=1e-13, atol=1e-10)
+    L_.check(L_.lib.tnf_set_option(L_.OPT_FLOW_VARIANT, 15))
+    try:
+        with torch.no_grad():
+            _, _, none = ops.flow_forward_raw(om, params.cuda(), mean, alpha, D, S, L, U, L_.FUSE_FLOW, want_log_q=True)
+        assert none is None
+    finally:
+        L_.check(L_.lib.tnf_set_option(L_.OPT_FLOW_VARIANT, DEFAULT_FLOW_VARIANT))
+
+
 def test_hip_graph_capture(tnf, oracle):
     """The C-ABI calls enqueue on torch's current stream and never synchronise or allocate, so a
     log_prob call can be captured into a HIP graph and replayed on new data."""

@@ -110,6 +110,8 @@ SIGNATURES = {
                                                      _i32, _i32, _i32, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tnf_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                             _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
+    "tnf_flow_forward_logq_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                                 _i32, _i32, _i64, _i32, _vp, _i64, _vp]),
 }
 
 

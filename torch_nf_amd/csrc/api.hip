@@ -1156,12 +1156,12 @@ int tnf_flow_forward_train_bwd_f32(const float* omega, const float* params, cons
                                          g_params, M, M_p, N, D, S, L, U, pstride, gpstride, workspace, as_stream(stream));
 }
 
-int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
+static int flow_forward_impl(const float* omega, const float* params, const float* bn_mean,
                          const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
                          int64_t M_z,
                          int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,
                          int64_t pstride, int32_t fusion, void* workspace, int64_t workspace_bytes,
-                         void* stream) {
+                         void* stream, double* log_q) {
     int use_fused = 0;
     int rc = flow_common_checks("tnf_flow_forward_f32", M_z, M_p, N, D, S, L, U, pstride, fusion,
                                 workspace, workspace_bytes, &use_fused);
@@ -1186,7 +1186,10 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
         return fail(TNF_EUNSUPPORTED, "tnf_flow_forward_f32: a fused support layer needs the whole-flow kernel");
     if (f16 && (g_flow_variant == 10 || g_flow_variant == 20) && flow_fused2_supported(D, S, L, U))  // f16_tile2.h, FWD
         return launch_flow_fused2(omega, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha,
-                                  interval_consts, nullptr, st, 1);
+                                  interval_consts, nullptr, st, 1, log_q);
+    if (log_q)
+        return fail(TNF_EUNSUPPORTED, "tnf_flow_forward_logq_f32: only the default whole-flow kernel writes log_q "
+                                      "(D=%d S=%d L=%d U=%d, fusion %d)", D, S, L, U, fusion);
     if (f16)
         return launch_flow_fused_f16(omega, nullptr, nullptr, nullptr, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L,
                                      U, 0, g_flow_variant, st, params, pstride, bn_mean, bn_alpha, interval_consts);
@@ -1224,6 +1227,25 @@ int tnf_flow_forward_f32(const float* omega, const float* params, const float* b
         if (rc) return rc;
     }
     return TNF_OK;
+}
+
+int tnf_flow_forward_f32(const float* omega, const float* params, const float* bn_mean,
+                         const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
+                         int64_t M_z,
+                         int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,
+                         int64_t pstride, int32_t fusion, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+    return flow_forward_impl(omega, params, bn_mean, bn_alpha, interval_consts, z_out, sum_log_det, M_z, M_p, N, D, S, L, U,
+                             pstride, fusion, workspace, workspace_bytes, stream, nullptr);
+}
+
+int tnf_flow_forward_logq_f32(const float* omega, const float* params, const float* bn_mean,
+                              const float* bn_alpha, const float* interval_consts, float* z_out, float* sum_log_det,
+                              double* log_q, int64_t M_z, int64_t M_p, int64_t N, int32_t D, int32_t S, int32_t L, int32_t U,
+                              int64_t pstride, int32_t fusion, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!log_q) return fail(TNF_EINVAL, "tnf_flow_forward_logq_f32: NULL log_q");
+    return flow_forward_impl(omega, params, bn_mean, bn_alpha, interval_consts, z_out, sum_log_det, M_z, M_p, N, D, S, L, U,
+                             pstride, fusion, workspace, workspace_bytes, stream, log_q);
 }
 
 }  // extern "C"

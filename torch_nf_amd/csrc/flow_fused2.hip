@@ -310,6 +310,23 @@ flow_fused2_kernel(Flow2Args a) {
                 hi[t][mm] = nhi[t][mm];
             }
         }
+        double bsq[NT];  // sampling pass with a.log_q: this lane's share of |omega|^2, float64 like the reference's base density
+        if constexpr (FWD) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bsq[t] = 0.0;
+                if (a.log_q) {
+#pragma unroll
+                    for (int mm = 0; mm < HT; ++mm)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const double vl = (double)lo[t][mm][j], vh = (double)hi[t][mm][j];
+                            bsq[t] = __builtin_fma(vl, vl, bsq[t]);
+                            bsq[t] = __builtin_fma(vh, vh, bsq[t]);
+                        }
+                }
+            }
+        }
         enter(lo, hi, ssup);
         if (has_next) load_group(nxt, nlo, nhi);
         run_layers2<H, L, NT, SS, false, FWD>(img, a.S, lane, lo, hi, ssum);
@@ -348,6 +365,15 @@ flow_fused2_kernel(Flow2Args a) {
                 if (q == 0 && row_ok) lpo[row] = -0.5f * sq - (float)D * 0.91893853320467274178f - ld_tot;
             }
             if (sldo && q == 0 && row_ok) sldo[row] = ld_tot;
+            if constexpr (FWD) {
+                if (a.log_q) {  // density_estimator.py:369-372, 387: log_q = log N(omega; 0, I) - sum of the forward log-dets
+                    double b = bsq[t];
+                    b += __shfl_xor(b, 16);
+                    b += __shfl_xor(b, 32);
+                    if (q == 0 && row_ok)
+                        a.log_q[m * a.N + row] = (-0.5 * b - (double)D * 0.91893853320467274178) - (double)ld_tot;
+                }
+            }
             if (zo && !a.stage_out && row_ok) {
                 float* zr = zo + row * D + 4 * q;
 #pragma unroll
@@ -855,7 +881,7 @@ static int launch2_v(const Flow2Args& a, int64_t M, int forward, hipStream_t st)
 int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
                        int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
                        const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st,
-                       int forward) {
+                       int forward, double* log_q) {
     if (!flow_fused2_supported(D, S, L, U))
         return fail(TNF_EUNSUPPORTED, "flow_fused2: no kernel for D=%d S=%d L=%d U=%d", D, S, L, U);
     if (N <= 0) return TNF_OK;
@@ -863,6 +889,7 @@ int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log
     const FlowLayout fl = flow_layout(D, S, L, U);
     Flow2Args a{z, z0, sum_log_det, log_prob, Mz, Mp, N, S, U, params, bn_mean, bn_alpha, pstride, fl.stage,
                 fl.p_up + fl.p_low, fl.p_up, interval_consts, slow_count};
+    a.log_q = forward ? log_q : nullptr;
     int rc;
     if (D == 64) rc = L == 1 ? launch2_v<32, 1>(a, M, forward, st) : (L == 2 ? launch2_v<32, 2>(a, M, forward, st) : launch2_v<32, 3>(a, M, forward, st));
     else rc = L == 1 ? launch2_v<16, 1>(a, M, forward, st) : (L == 2 ? launch2_v<16, 2>(a, M, forward, st) : launch2_v<16, 3>(a, M, forward, st));

@@ -143,6 +143,8 @@ struct Flow2Args {
     const float* iv;     // (7, D) constants of a fused ToInterval support layer, or NULL
     unsigned* slow_count;  // optional: += number of groups re-run through the exact path (testing / diagnostics)
     int stage_out;         // set by the launcher: row outputs leave through LDS staging tiles (flow_fused2.hip)
+    double* log_q;         // sampling pass, optional: log N(omega; 0, I) - (sum of log-dets), (M, N) float64 -- the
+                           // log-density NormFlow.forward returns beside the samples (density_estimator.py:369-388)
 };
 
 bool flow_fused2_supported(int D, int S, int L, int U);
@@ -150,7 +152,7 @@ bool flow_fused2_supported(int D, int S, int L, int U);
 int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
                        int D, int S, int L, int U, const float* params, int64_t pstride, const float* bn_mean,
                        const float* bn_alpha, const float* interval_consts, unsigned* slow_count, hipStream_t st,
-                       int forward = 0);
+                       int forward = 0, double* log_q = nullptr);
 // the same tile code as a chain of launches with `per_launch` coupling layers each (1 = one kernel per coupling layer)
 bool flow_fused3_supported(int D, int S, int L, int U);  // flow_fused3.hip: the same on 32-sample groups (32x32x16 MFMAs)
 int launch_flow_fused3(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,

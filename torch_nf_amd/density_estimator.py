@@ -259,9 +259,14 @@ class NormFlow(DensityEstimator):
         the 8 B/value PCIe copy)."""
         home = params.device
         dev = _lib.require_device()
+        p_dev = params if params.device == dev else params.to(dev)
+        log_q = None
         if torch.is_tensor(omega) and omega.dtype == torch.float32:
             z = omega.detach().to(dev)  # device-side draw: no float64 round trip
-            log_q = ops.base_log_density_f64(z)
+            # the base density of a float32 draw can come out of the whole-flow sampling kernel itself (below);
+            # every other route evaluates it here
+            if not (freeze_bn and self._fused_ok(z, p_dev) and self._whole_flow()):
+                log_q = ops.base_log_density_f64(z)
         else:
             if torch.is_tensor(omega):
                 omega64 = omega.detach().to(device=dev, dtype=torch.float64)
@@ -269,7 +274,6 @@ class NormFlow(DensityEstimator):
                 omega64 = torch.as_tensor(np.ascontiguousarray(omega), dtype=torch.float64).to(dev)
             z = omega64.float()
             log_q = ops.base_log_density_f64(omega64)
-        p_dev = params if params.device == dev else params.to(dev)
 
         sup = self._fused_support()
         support_done = False
@@ -288,10 +292,18 @@ class NormFlow(DensityEstimator):
         elif freeze_bn and self._fused_ok(z, p_dev):
             mean, alpha = self._bn_stats(dev)
             fuse_sup = (sup is not None and sup is not False and self._whole_flow())
-            z, sld = ops.flow_forward_raw(z, p_dev, mean, alpha, self.D, self.num_stages,
-                                          self.num_layers, self.num_units, self.fusion,
-                                          interval_consts=sup if fuse_sup else None)
-            log_q = log_q - sld
+            if log_q is None:  # float32 device draw on the whole-flow kernel: it writes log N(omega) - sld itself
+                omega_dev = z
+                z, sld, log_q = ops.flow_forward_raw(z, p_dev, mean, alpha, self.D, self.num_stages, self.num_layers,
+                                                     self.num_units, self.fusion,
+                                                     interval_consts=sup if fuse_sup else None, want_log_q=True)
+                if log_q is None:
+                    log_q = ops.base_log_density_f64(omega_dev) - sld
+            else:
+                z, sld = ops.flow_forward_raw(z, p_dev, mean, alpha, self.D, self.num_stages,
+                                              self.num_layers, self.num_units, self.fusion,
+                                              interval_consts=sup if fuse_sup else None)
+                log_q = log_q - sld
             support_done = fuse_sup
         elif (not freeze_bn and self._fused_ok(z, p_dev) and self._batch_chain_ok(z, p_dev)
               and (z.size(0) * z.size(1) > 1 or self.batch_stats_reduce is not None)):

@@ -411,8 +411,11 @@ def flow_log_prob_raw(z, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE
     return (lp, z0, sld, reruns) if count_reruns else (lp, z0, sld)
 
 
-def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO, interval_consts=None):
-    """tnf_flow_forward_f32 (frozen BatchNorm).  Returns (z (M,N,D), sum_log_det (M,N))."""
+def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.FUSE_AUTO, interval_consts=None,
+                     want_log_q=False):
+    """tnf_flow_forward_f32 (frozen BatchNorm).  Returns (z (M,N,D), sum_log_det (M,N)).
+    want_log_q: a third value, log_q (M,N) float64 = log N(omega; 0, I) - sum_log_det written by the whole-flow kernel
+    itself (tnf_flow_forward_logq_f32), or None when the call does not run on that kernel."""
     _check3(omega)
     dev = _lib.require_device()
     home = omega.device
@@ -429,16 +432,30 @@ def flow_forward_raw(omega, params, bn_mean, bn_alpha, D, S, L, U, fusion=_lib.F
     z_out = torch.empty((M, N, D), dtype=torch.float32, device=dev)
     sld = torch.empty((M, N), dtype=torch.float32, device=dev)
     if N == 0:
-        return z_out.to(home), sld.to(home)
+        out = (z_out.to(home), sld.to(home))
+        return out + (torch.empty((M, N), dtype=torch.float64, device=home),) if want_log_q else out
     ws_bytes = check(lib.tnf_flow_workspace_bytes(M, N, D, S, L, U, fusion))
     ws = _workspace(ws_bytes, dev)
-    check(lib.tnf_flow_forward_f32(oc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
-                                   None if interval_consts is None else interval_consts.data_ptr(),
-                                   z_out.data_ptr(), sld.data_ptr(), Mz, Mp, N, D, S, L, U, pstride,
-                                   fusion, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    log_q = None
+    if want_log_q and fusion == _lib.FUSE_FLOW:
+        log_q = torch.empty((M, N), dtype=torch.float64, device=dev)
+        rc = lib.tnf_flow_forward_logq_f32(oc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+                                           None if interval_consts is None else interval_consts.data_ptr(),
+                                           z_out.data_ptr(), sld.data_ptr(), log_q.data_ptr(), Mz, Mp, N, D, S, L, U,
+                                           pstride, fusion, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        if rc == _lib.EUNSUPPORTED:
+            log_q = None  # a selectable variant without that output: the plain entry below, the caller adds the density
+        else:
+            check(rc)
+    if log_q is None:
+        check(lib.tnf_flow_forward_f32(oc.data_ptr(), pc.data_ptr(), mean_c.data_ptr(), alpha_c.data_ptr(),
+                                       None if interval_consts is None else interval_consts.data_ptr(),
+                                       z_out.data_ptr(), sld.data_ptr(), Mz, Mp, N, D, S, L, U, pstride,
+                                       fusion, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
     if home != dev:
         z_out, sld = z_out.to(home), sld.to(home)
-    return z_out, sld
+        log_q = None if log_q is None else log_q.to(home)
+    return (z_out, sld, log_q) if want_log_q else (z_out, sld)
 
 
 # ---------------------------------------------------------------------------
