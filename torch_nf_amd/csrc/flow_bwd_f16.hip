@@ -237,6 +237,38 @@ __device__ __forceinline__ T16 mtrans(h4 hi, h4 lo, h4 ident) {
     o.lo = pack4(mfma16h(lo, ident, zero));
     return o;
 }
+// The same through LDS with gfx950's transposing read: every lane stores its four f16 (rows 4q .. 4q+3 of column s)
+// into a [sample][row] image with 32-byte rows, and ds_read_b64_tr_b16 hands lane (c, kq) the samples 4kq .. 4kq+3 of
+// row c (cdna_hip_programming.md T10: per 16-lane group a 4-row x 16-column block, delivered column-major) -- two LDS
+// instructions per half tile, no matrix or vector instruction.  scr: this wave's scratch tile (>= 1 KB); the wave's LDS
+// instructions execute in order.  Needs all 64 lanes active (the tile code has no divergent branches).
+// Measured (N = 2^19, steady state): backward 0.677 ms with these reads against 0.628 ms with the MFMA transposes -- the
+// kernel's LDS pipe (atomics, image reads, the activation transposes) is the busier one.  Kept selectable, off.
+#ifndef TNF_REV_LTRANS
+#define TNF_REV_LTRANS 0
+#endif
+__device__ __forceinline__ h4 tr_read16(const _Float16* p) {
+    typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    return __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p));
+}
+__device__ __forceinline__ T16 ltrans(h4 hi, h4 lo, h4 ident, float* scr, int lane) {
+#if TNF_REV_LTRANS
+    (void)ident;
+    _Float16* t = reinterpret_cast<_Float16*>(scr);  // [hi | lo][16 samples][16 rows]
+    const int s = lane & 15, q = lane >> 4;
+    *reinterpret_cast<h4*>(t + s * 16 + 4 * q) = hi;
+    *reinterpret_cast<h4*>(t + 256 + s * 16 + 4 * q) = lo;
+    const _Float16* a = t + (4 * q + (s >> 2)) * 16 + 4 * (s & 3);  // group q, lane s of it: image row 4q + s/4, columns 4 (s%4) ..
+    T16 o;
+    o.hi = tr_read16(a);
+    o.lo = tr_read16(a + 256);
+    return o;
+#else
+    (void)scr;
+    (void)lane;
+    return mtrans(hi, lo, ident);
+#endif
+}
 // D[rows of a][rows of b] = sum over the 16 samples
 __device__ __forceinline__ f4 outer16h(const T16& a, const T16& b) {
     f4 acc = mfma16h(a.hi, b.hi, f4{0.f, 0.f, 0.f, 0.f});
@@ -571,7 +603,7 @@ __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float*
 #pragma unroll
         for (int mo = 0; mo < HT; ++mo) {
             split4(dout[net][mo], dsh[mo], dsl[mo]);
-            const T16 d_t = mtrans(dsh[mo], dsl[mo], ident);
+            const T16 d_t = ltrans(dsh[mo], dsl[mo], ident, scrA, lane);
             accp.w2(net, mo, d_t, h_t);  // [o = 16 mo + 4q + j][k = s]
             if (!SPARE) accp.b2(net, mo, d_t);
         }
@@ -604,7 +636,7 @@ __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float*
             }
             h4 dhi, dlo;
             split4(da, dhi, dlo);
-            const T16 d_t = mtrans(dhi, dlo, ident);
+            const T16 d_t = ltrans(dhi, dlo, ident, scrA, lane);
             const T16 h_t = tsplit(with_ones(h[l][net]), scrB, lane);
             accp.wh(l, net, d_t, h_t);  // [k_out = 4q + j][k_in = s]
             if (!SPARE) accp.bh(l, net, d_t);
@@ -615,7 +647,7 @@ __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float*
     // ---- 5. first layer: dW0, db0, d x ----
     T16 x_t[HT];
 #pragma unroll
-    for (int mm = 0; mm < HT; ++mm) x_t[mm] = mtrans(xs_hi[mm], xs_lo[mm], ident);
+    for (int mm = 0; mm < HT; ++mm) x_t[mm] = ltrans(xs_hi[mm], xs_lo[mm], ident, scrA, lane);
 #pragma unroll
     for (int net = 0; net < 2; ++net) {
         f4 da;
@@ -626,7 +658,7 @@ __device__ __forceinline__ void layer_bwd16(const float* img, ACCP& accp, float*
         }
         h4 dhi, dlo;
         split4(da, dhi, dlo);
-        const T16 d_t = mtrans(dhi, dlo, ident);
+        const T16 d_t = ltrans(dhi, dlo, ident, scrA, lane);
         accp.b0(net, d_t);
 #pragma unroll
         for (int mm = 0; mm < HT; ++mm) {
