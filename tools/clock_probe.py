@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Shader clock held under the whole-flow kernel's own load (MI355X_MICROARCH.md, 'DVFS give-back' item 6).
 Needs a DIAGNOSTIC build of libtnf_hip.so with -DTNF2_STAMP=1 (flow_fused2.hip: s_memtime / s_memrealtime stamps around
-the main loop, written to the diagnostic counter buffer; never shipped):  TNF_LIB_PATH=<that library> python tools/clock_probe.py
+the main loop, written to the diagnostic counter buffer; never shipped):
+  make -C torch_nf_amd/csrc stamp && TNF_LIB_PATH=torch_nf_amd/lib/libtnf_hip_stamp.so python tools/clock_probe.py
 Runs the kernel back to back for ~3 s on random data, then reports the median over workgroups of
 delta(s_memtime) / delta(s_memrealtime) x 100 MHz for the last launch, next to the same figure for a memory-bound launch
 (the per-layer chain kernel cannot be stamped this way; its clock is read from GRBM_GUI_ACTIVE in profiles/r02_pmc.json)."""
