@@ -15,7 +15,13 @@ A "step" is one NormFlow.log_prob call over one (1, 2^20, 64) batch through the 
 with N GPUs every rank evaluates its own 2^20-sample batch (weak scaling) and `value` is
 the samples all ranks processed per second of the slowest rank.
 
+Timing protocol: every timed row is  settle (--settle-ms of the same call back to back: an MI355X that has been idle
+needs ~50 ms of load to reach the clock it holds)  ->  W warm-up steps  ->  barrier + synchronize ->
+K timed steps  ->  barrier + synchronize; `value` comes from that.  The contract's literal W + K steps on the idle GPU
+run first and are reported as `cold_start`.
+
 One JSON line is printed by rank 0.  Besides the contract's keys it carries
+  steady_state, cold_start -- the protocol above and the cold figure;
   roofline      -- the dominant kernel of the timed path, from HIP events recorded on the
                    stream the kernels run on, inside the timed region;
   cpu_baseline  -- the PyTorch-CPU oracle (oracle/flow_oracle.py, verified equal to the
@@ -28,7 +34,8 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
   rccl_ranks    -- sum over ranks of 1 through an RCCL all-reduce (proves N ranks took part);
   strong_scaling-- the same call with N = 2^20 samples IN TOTAL split over the ranks (north_star quotes both);
   train_step    -- BASELINE configs[3] per GPU: -mean(log_prob) on 2^19 samples, backward (reversible pair), Adam
-                   (with N GPUs: + the RCCL all-reduce of the flat gradient), outside the timed region;
+                   (with N GPUs: + the RCCL all-reduce of the flat gradient), outside the timed region; also with the
+                   backward's overflow recovery off / by host read-back, and replayed as one HIP graph;
   configs       -- (1 GPU) BASELINE configs[1] (D = 32, own roofline) and configs[2] (ConditionalDensityEstimator,
                    (M, N) = (16, 2^16): frozen forward + log_prob);
   widened       -- (1 GPU) the SURVEY 8f rows: fused conditional flow, AR log_prob, the LFI step as a HIP graph,
