@@ -74,6 +74,25 @@ enum {
                                  * contraction) -- the precision experiment of BASELINE configs[4], not a parity path */
 };
 int tnf_set_option(int32_t key, int32_t value);
+/* The calling thread's value of a key (options are per thread).  A caller that hands work to another thread -- the
+ * Python binding's autograd Functions run their backward on autograd's device thread -- reads the options where the
+ * forward ran and re-enters them where the backward runs. */
+int tnf_get_option(int32_t key, int32_t* value);
+
+/* Diagnostics: how many launches of a backward-kernel family this PROCESS has enqueued so far (any thread, any
+ * stream).  Tests that select a kernel through an option read the counters around a step to prove the intended kernel
+ * ran (a backward runs on autograd's thread, where a thread-local option set elsewhere would be silently absent). */
+enum {
+    TNF_DIAG_BWD_LAYER_FP32 = 0,  /* coupling_bwd_mfma_kernel: fp32-MFMA layer backward */
+    TNF_DIAG_BWD_LAYER_F16 = 1,   /* coupling_bwd_f16_kernel: split-f16 layer backward */
+    TNF_DIAG_BWD_GENERIC = 2,     /* coupling_backward_kernel<T>: shape-generic layer backward */
+    TNF_DIAG_BWD_FLOW_REV = 3,    /* flow_bwd_f16_kernel: one-kernel reversible backward */
+    TNF_DIAG_MAF_BWD_MFMA = 4,    /* maf_bwd_mfma_kernel */
+    TNF_DIAG_MAF_BWD_GENERIC = 5, /* maf_backward_kernel<T> */
+    TNF_DIAG_BWD_WIDE = 6,        /* coupling_wide_bwd_kernel: MFMA backward of the wide coupling shapes */
+    TNF_DIAG_FAMILIES = 8
+};
+int64_t tnf_diag_launch_count(int32_t family);
 
 /* Conditionally needed launches.  While a gate is set (per thread; NULL clears it), the layer kernels launched by
  * tnf_flow_log_prob_fwd_f32 / tnf_flow_log_prob_bwd_f32 read *flag on the device and return at once while it is 0:
@@ -188,25 +207,6 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
                      const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N,
                      int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                      int64_t g_params_row_stride, void* stream);
-
-/* ---- conditional flow, one sample per context (SNPE layout) ------------- */
-/* ConditionalDensityEstimator.log_prob(z[:, None, :], x) (conditional_density_estimator.py:101-104)
- * with the last Linear of param_net fused into the flow: params[m] = W . h[m] + b is generated
- * tile by tile on the matrix cores and consumed immediately, the (M, D_params) tensor never exists.
- *   z (M, D) float32; h (M, ldh) float32, the first H columns = output of param_net's last activation;
- *   W (D_params, ldw) / b (D_params) = weight / bias of param_net's last Linear (torch layout);
- *   bn_mean / bn_alpha (2*S, D); log_prob (M); z0 (M, D) and sum_log_det (M) optional (NULL).
- * Supported (tnf_cond_flow_supported): arch_type "coupling", D in {32, 64}, num_units <= 16,
- * num_layers <= 5, H in {32, 64, 128} (pad h and W with zero columns for other widths).
- * Rows of h and W must be 16-byte aligned (ldh, ldw multiples of 4). */
-int tnf_cond_flow_supported(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units, int32_t H);
-int64_t tnf_cond_flow_workspace_bytes(int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units,
-                                      int32_t H);
-int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, const float* b,
-                               const float* bn_mean, const float* bn_alpha, float* log_prob, float* z0,
-                               float* sum_log_det, int64_t M, int32_t D, int32_t num_stages, int32_t num_layers,
-                               int32_t num_units, int32_t H, int64_t ldh, int64_t ldw, void* workspace,
-                               int64_t workspace_bytes, void* stream);
 
 /* ---- conditional flow, one sample per context (SNPE layout) ------------- */
 /* ConditionalDensityEstimator.log_prob(z[:, None, :], x) (conditional_density_estimator.py:101-104)

@@ -265,11 +265,22 @@ def test_forward_path_training_one_node(tnf, oracle, D, S, L, M, N, fp32_bwd):
     om0 = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
     w = torch.tensor(rng.uniform(0.5, 1.5, (M, N))).float()
     # the layer backward kernel of the chain: split-f16 (default) or fp32 MFMA
-    tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, fp32_bwd))
+    # (the option is thread-local and backward runs on autograd's thread: the Functions re-enter the forward's options
+    # there, and the launch counters prove which layer kernel really ran)
+    lib = tnf._lib.lib
+    before = [lib.tnf_diag_launch_count(f) for f in (tnf._lib.DIAG_BWD_LAYER_FP32, tnf._lib.DIAG_BWD_LAYER_F16)]
+    tnf._lib.check(lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, fp32_bwd))
     try:
         _one_node_body(tnf, oracle, nf, p0, om0, w, D, S, L, U)
     finally:
-        tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, 0)
+        lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, 0)
+    ran = [lib.tnf_diag_launch_count(f) - b for f, b in
+           zip((tnf._lib.DIAG_BWD_LAYER_FP32, tnf._lib.DIAG_BWD_LAYER_F16), before)]
+    # two one-node backwards of 2S layers each; the per-bijector comparison leg adds 2S fp32-MFMA layer launches either way
+    if fp32_bwd:
+        assert ran[0] >= 6 * S and ran[1] == 0, ran
+    else:
+        assert ran[1] == 4 * S and ran[0] == 2 * S, ran
 
 
 def _one_node_body(tnf, oracle, nf, p0, om0, w, D, S, L, U):
@@ -357,15 +368,24 @@ def test_training_step_full_size_properties(tnf):
         b.set_last_stats(torch.tensor(rng.normal(0, 0.3, D)).float(), torch.tensor(np.exp(rng.normal(0, 0.2, D))).float())
     z = torch.randn(1, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
 
+    lib = tnf._lib.lib
+    fams = (tnf._lib.DIAG_BWD_FLOW_REV, tnf._lib.DIAG_BWD_LAYER_F16, tnf._lib.DIAG_BWD_LAYER_FP32)
+    tnf.ops._FlowLogProbRevFn.overflow_recovery = "off"  # (its gated fp32 fallback would blur the launch counts)
+
     def grad(reversible, fp32, scale=1.0):
-        tnf._lib.check(tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, fp32))
+        before = [lib.tnf_diag_launch_count(f) for f in fams]
+        tnf._lib.check(lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, fp32))
         try:
             nf.reversible_training = reversible
             nf.params = p0.clone().requires_grad_()
             (-nf.log_prob(z).mean() * scale).backward()
-            return nf.params.grad.clone()
+            g = nf.params.grad.clone()
         finally:
-            tnf._lib.lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, 0)
+            lib.tnf_set_option(tnf._lib.OPT_TRAIN_BWD_FP32, 0)
+        ran = [lib.tnf_diag_launch_count(f) - b for f, b in zip(fams, before)]
+        want = 0 if reversible else (2 if fp32 else 1)  # the implementation this leg is meant to exercise ...
+        assert ran[want] >= 1 and all(r == 0 for i, r in enumerate(ran) if i != want), (reversible, fp32, ran)
+        return g
 
     g_rev, g_l16, g_l32 = grad(True, 0), grad(False, 0), grad(False, 1)
     top = float(g_l32.abs().max())
@@ -373,7 +393,10 @@ def test_training_step_full_size_properties(tnf):
     assert float((g_rev - g_l32).abs().max()) <= 2e-5 * top
     assert float((g_l16 - g_l32).abs().max()) <= 2e-5 * top
     a = 0.37 / 1024.0
-    assert float((grad(True, 0, a) / a - g_rev).abs().max()) <= 2e-5 * top
+    try:
+        assert float((grad(True, 0, a) / a - g_rev).abs().max()) <= 2e-5 * top
+    finally:
+        tnf.ops._FlowLogProbRevFn.overflow_recovery = "device"
 
 
 @pytest.mark.parametrize("M,Mp,N", [(1, 1, 1 << 17), (3, 1, 5000), (4, 4, 3000)])
@@ -511,8 +534,9 @@ def test_overflow_recovery_inside_a_hip_graph(tnf, oracle):
     torch.testing.assert_close(g_bad.cpu() / scale, p_ref.grad / scale, rtol=2e-3, atol=2e-5)
 
 
+@pytest.mark.parametrize("home", ["cuda", "cpu"])
 @pytest.mark.parametrize("arch,D,S", [("coupling", 64, 2), ("coupling", 6, 1), ("AR", 6, 1)])
-def test_bn_statistics_stay_in_graph(tnf, oracle, arch, D, S):
+def test_bn_statistics_stay_in_graph(tnf, oracle, arch, D, S, home):
     """The reference caches last_mean / last_alpha WITHOUT detach (bijectors.py:414-415): `nf(N)` followed by
     `nf.log_prob(z)` (or the inverse) in one graph back-propagates through the batch moments of the sampling call.
     The per-bijector path (nf.fused_batch_forward = False) keeps that behaviour; log_prob notices statistics that are
@@ -547,10 +571,13 @@ def test_bn_statistics_stay_in_graph(tnf, oracle, arch, D, S):
 
     loss_ref, g_ref = oracle_loss(False)
     _, g_det = oracle_loss(True)
-    p = p0.cuda().requires_grad_()
+    # home = "cpu": a caller of the reference -- host tensors in, host tensors out; the cached statistics then live on
+    # the host WITH their graph and the staged device copies must stay differentiable
+    p = p0.to(home).requires_grad_()
     z, lq = nf._forward_from(omega, p, freeze_bn=False)
     assert all(b.get_last_alpha().requires_grad for b in nf._bn_layers())
-    lp = nf.log_prob(z_eval.cuda(), p)
+    assert all(b.get_last_alpha().device.type == home for b in nf._bn_layers())
+    lp = nf.log_prob(z_eval.to(home), p)
     loss = lq.mean() + 0.5 * lp.double().mean() + 0.1 * (z.double() ** 2).mean()
     loss.backward()
     scale = float(g_ref.abs().max())
@@ -561,3 +588,58 @@ def test_bn_statistics_stay_in_graph(tnf, oracle, arch, D, S):
     for b in nf._bn_layers():
         b.set_last_stats(b.get_last_mean(), b.get_last_alpha())
     assert not nf._stats_in_graph()
+
+
+def test_cde_fused_conditioner_respects_statistics_in_graph(tnf, oracle):
+    """`cde(x, N)` with fresh batch statistics under autograd, then `cde.log_prob(z[:, None, :], x)` in the SAME graph
+    (conditional_density_estimator.py:93-104 over bijectors.py:414-415): the one-sample-per-context call would take the
+    fused conditioner + flow kernels, which treat the statistics as constants -- it must stand back while they carry a
+    graph.  Gradient w.r.t. param_net against torch autograd over the oracle, and measurably different from the
+    detached-statistics gradient."""
+    D, S, L, U, Dx, M, N = 64, 2, 2, 15, 8, 48, 6
+    rng = np.random.RandomState(5)
+    torch.manual_seed(0)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    nf.fused_batch_forward = False
+    cde = tnf.ConditionalDensityEstimator(nf, Dx, [32])
+    for prm in cde.param_net.parameters():
+        prm.data.mul_(0.3)
+    x = torch.tensor(rng.normal(0, 1, (M, Dx))).float()
+    omega = rng.normal(0, 1, (M, N, D))
+    z_eval = torch.tensor(rng.normal(0, 1, (M, 1, D))).float()
+    assert M >= cde.fuse_min_contexts
+
+    import copy
+
+    ref_net = copy.deepcopy(cde.param_net).cpu()
+
+    def oracle_grads(detach):
+        ref_net.zero_grad()
+        p = ref_net(x)
+        z, lq, st = oracle.flow_forward(omega, p, D, S, L, U, None)
+        if detach:
+            st = [(m.detach(), a.detach()) for m, a in st]
+        lp = oracle.flow_log_prob(z_eval, p, D, S, L, U, st)
+        loss = lq.mean() + 0.5 * lp.double().mean()
+        loss.backward()
+        return float(loss.detach()), torch.cat([q.grad.reshape(-1) for q in ref_net.parameters()])
+
+    loss_ref, g_ref = oracle_grads(False)
+    _, g_det = oracle_grads(True)
+    xd = x.cuda()
+    params = cde._params_for(xd)
+    z, lq = nf._forward_from(omega, params, freeze_bn=False)
+    assert nf._stats_in_graph()
+    assert not cde._fused_conditioner_ok(z_eval.cuda(), xd)
+    lp = cde.log_prob(z_eval.cuda(), xd)
+    loss = lq.mean() + 0.5 * lp.double().mean()
+    loss.backward()
+    g = torch.cat([q.grad.reshape(-1) for q in cde.param_net.parameters()]).cpu()
+    scale = float(g_ref.abs().max())
+    assert abs(float(loss.detach()) - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
+    assert float((g_det - g_ref).abs().max()) > 1e-3 * scale, "detached statistics must give a different gradient"
+    torch.testing.assert_close(g / scale, g_ref / scale, rtol=5e-3, atol=2e-5)
+    # constants again -> the fused conditioner comes back
+    for b in nf._bn_layers():
+        b.set_last_stats(b.get_last_mean(), b.get_last_alpha())
+    assert cde._fused_conditioner_ok(z_eval.cuda(), xd)

@@ -197,6 +197,7 @@ def test_maf_backward_mfma(tnf, oracle, D, L, U, Mz, Mp, N):
     ((zo * wz).sum() + (ld * wl).sum()).backward()
     grads = []
     for generic in (0, 1):
+        before = [_lib.lib.tnf_diag_launch_count(f) for f in (_lib.DIAG_MAF_BWD_MFMA, _lib.DIAG_MAF_BWD_GENERIC)]
         _lib.lib.tnf_set_option(_lib.OPT_FORCE_GENERIC, generic)
         try:
             p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
@@ -205,6 +206,10 @@ def test_maf_backward_mfma(tnf, oracle, D, L, U, Mz, Mp, N):
             grads.append((z.grad.cpu(), p.grad.cpu()))
         finally:
             _lib.lib.tnf_set_option(_lib.OPT_FORCE_GENERIC, 0)
+        # backward runs on autograd's thread; the Function re-enters the forward's options there -- prove it
+        ran = [_lib.lib.tnf_diag_launch_count(f) - b for f, b in
+               zip((_lib.DIAG_MAF_BWD_MFMA, _lib.DIAG_MAF_BWD_GENERIC), before)]
+        assert ran[generic] == 1 and ran[1 - generic] == 0, (generic, ran)
 
     def close(a, b, tol):
         scale = float(b.abs().max().clamp_min(1e-30))

@@ -19,6 +19,8 @@ FUSE_AUTO, FUSE_LAYER, FUSE_FLOW = 0, 1, 2
 OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT, OPT_COND_VARIANT, OPT_TRAIN_BWD_FP32 = 1, 2, 3, 4, 5
 OPT_OPERAND_PREC = 6
 EUNSUPPORTED = -2
+DIAG_BWD_LAYER_FP32, DIAG_BWD_LAYER_F16, DIAG_BWD_GENERIC, DIAG_BWD_FLOW_REV = 0, 1, 2, 3
+DIAG_MAF_BWD_MFMA, DIAG_MAF_BWD_GENERIC, DIAG_BWD_WIDE = 4, 5, 6
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
@@ -27,6 +29,8 @@ SIGNATURES = {
     "tnf_version": (ctypes.c_int, []),
     "tnf_last_error": (ctypes.c_char_p, []),
     "tnf_set_option": (ctypes.c_int, [_i32, _i32]),
+    "tnf_get_option": (ctypes.c_int, [_i32, _vp]),
+    "tnf_diag_launch_count": (_i64, [_i32]),
     "tnf_set_launch_gate": (ctypes.c_int, [_vp]),
     "tnf_gated_copy_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "tnf_coupling_num_params": (_i64, [_i32, _i32, _i32, _i32]),
@@ -143,6 +147,42 @@ def check(rc):
     if rc < 0:
         raise TnfError(rc, lib.tnf_last_error().decode("utf-8", "replace"))
     return rc
+
+
+_OPTION_KEYS = (OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT, OPT_COND_VARIANT, OPT_TRAIN_BWD_FP32,
+                OPT_OPERAND_PREC)
+
+
+def options_snapshot():
+    """The calling thread's tnf_set_option values (options are thread-local in the library)."""
+    out = []
+    val = ctypes.c_int32(0)
+    for key in _OPTION_KEYS:
+        check(lib.tnf_get_option(key, ctypes.addressof(val)))
+        out.append(val.value)
+    return tuple(out)
+
+
+class options_reentered(object):
+    """`with options_reentered(snapshot)`: run a block under the options another thread had.  autograd calls
+    Function.backward on its own device thread, where every option is still at its default: the Functions in ops.py
+    record options_snapshot() in forward and re-enter it in backward, so a kernel variant chosen for a training step
+    (TNF_OPT_TRAIN_BWD_FP32, TNF_OPT_FORCE_GENERIC, the operand precision) governs both of its halves."""
+
+    def __init__(self, snapshot):
+        self.snapshot = snapshot
+
+    def __enter__(self):
+        self.before = options_snapshot()
+        if self.before != self.snapshot:
+            for key, value in zip(_OPTION_KEYS, self.snapshot):
+                check(lib.tnf_set_option(key, value))
+
+    def __exit__(self, *exc):
+        if self.before != self.snapshot:
+            for key, value in zip(_OPTION_KEYS, self.before):
+                lib.tnf_set_option(key, value)
+        return False
 
 
 def require_device():

@@ -227,6 +227,10 @@ class BatchNorm(Bijector):
         dev = torch.device("cuda", torch.cuda.current_device())
         if self._last_mean.device == dev:
             return self._last_mean, self._last_alpha
+        if torch.is_grad_enabled() and (self._last_mean.requires_grad or self._last_alpha.requires_grad):
+            # host-resident statistics that still carry the graph of their batch-mode forward (a CPU caller, like every
+            # caller of the reference): a differentiable copy, never the detached cache (bijectors.py:414-415)
+            return self._last_mean.float().to(dev), self._last_alpha.float().to(dev)
         key = (self._version, dev)
         if getattr(self, "_dev_key", None) != key:
             self._dev_stats = (self._last_mean.detach().float().to(dev), self._last_alpha.detach().float().to(dev))

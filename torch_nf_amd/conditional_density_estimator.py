@@ -117,6 +117,8 @@ class ConditionalDensityEstimator(torch.nn.Module):
             return False
         if nf.arch_type != "coupling" or nf.support_layer is not None or z.size(2) != nf.D:
             return False
+        if nf._stats_in_graph():
+            return False  # the fused kernels treat the statistics as constants (bijectors.py:414-415 keeps their graph)
         if z.dtype != torch.float32 or x.dtype != torch.float32 or last.weight.dtype != torch.float32:
             return False
         return ops.cond_flow_supported(nf.D, nf.num_stages, nf.num_layers, nf.num_units, last.in_features)

@@ -2,6 +2,8 @@
 // kernel selection and the launch sequences of the flow-level chains.
 #include <string.h>
 
+#include <atomic>
+
 #include "tnf_common.h"
 
 namespace tnf {
@@ -9,6 +11,11 @@ namespace tnf {
 thread_local int g_force_generic = 0;
 thread_local int g_operand_prec = 0;
 thread_local const int* g_launch_gate = nullptr;
+
+static std::atomic<long long> g_diag_launches[TNF_DIAG_FAMILIES];
+void diag_count(int family) {
+    if (family >= 0 && family < TNF_DIAG_FAMILIES) g_diag_launches[family].fetch_add(1, std::memory_order_relaxed);
+}
 
 char* err_buf() {
     static thread_local char buf[512] = {0};
@@ -48,14 +55,22 @@ static int64_t flow_image_slot(int D, int L, int U) {
     // narrow shapes: fp32 and split-f16 images share one slot size (the L = 3 fp32 image);
     // wide shapes: the wide image of exactly this (D, L, U)
     if (!mfma_supported(D, L, U)) return wide_image_floats(D, L, U);
-    // narrow shapes: fp32 and split-f16 images share one slot size (the L = 3 fp32 image); the prepared prologues of the
-    // layer-range chain (flow_chain2_prep_floats / 2S per layer at one layer per launch, less with more) fit it too
+    // narrow shapes: fp32 and split-f16 images share one slot size (the L = 3 fp32 image); flow_ws takes the larger of
+    // this and flow_prep_slot (the layer-range chain's prepared prologues)
     const int64_t a = mfma_image_floats(D, 3);
     return a;
 }
-static int64_t flow_prep_slot(int D, int S, int L, int U) {  // per layer, so that 2S slots hold a chain's prepared prologues
+static int64_t flow_prep_slot(int D, int S, int L, int U) {
+    // per layer, so that 2S slots hold a chain's prepared prologues -- for EVERY number of layers per launch the chain
+    // accepts (TNF_OPT_LAYER_VARIANT 10 + n): a launch's region grows with n faster than the number of launches falls
     if (!mfma_supported(D, L, U)) return 0;
-    return (flow_chain2_prep_floats(D, S, L, 1) + 2 * S - 1) / (2 * S);
+    int64_t most = 0;
+    for (int n = 1; n <= 2 * S; ++n) {
+        if (!flow_range2_supported(D, L, U, n)) break;
+        const int64_t need = flow_chain2_prep_floats(D, S, L, n);
+        if (need > most) most = need;
+    }
+    return (most + 2 * S - 1) / (2 * S);
 }
 static FlowWs flow_ws(int64_t M, int64_t N, int D, int S, int L, int U) {
     FlowWs w;
@@ -127,6 +142,24 @@ int tnf_set_option(int32_t key, int32_t value) {
         return TNF_OK;
     }
     return fail(TNF_EINVAL, "tnf_set_option: unknown key %d", key);
+}
+
+int64_t tnf_diag_launch_count(int32_t family) {
+    if (family < 0 || family >= TNF_DIAG_FAMILIES) return fail(TNF_EINVAL, "tnf_diag_launch_count: family %d", family);
+    return g_diag_launches[family].load(std::memory_order_relaxed);
+}
+
+int tnf_get_option(int32_t key, int32_t* value) {
+    if (!value) return fail(TNF_EINVAL, "tnf_get_option: value is NULL");
+    switch (key) {
+        case TNF_OPT_FORCE_GENERIC: *value = g_force_generic; return TNF_OK;
+        case TNF_OPT_FLOW_VARIANT: *value = g_flow_variant; return TNF_OK;
+        case TNF_OPT_LAYER_VARIANT: *value = g_layer_variant; return TNF_OK;
+        case TNF_OPT_COND_VARIANT: *value = g_cond_variant; return TNF_OK;
+        case TNF_OPT_TRAIN_BWD_FP32: *value = g_train_bwd_fp32; return TNF_OK;
+        case TNF_OPT_OPERAND_PREC: *value = g_operand_prec; return TNF_OK;
+    }
+    return fail(TNF_EINVAL, "tnf_get_option: unknown key %d", key);
 }
 
 int64_t tnf_coupling_num_params(int32_t D, int32_t L, int32_t U, int32_t upper) {

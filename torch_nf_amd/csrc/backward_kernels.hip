@@ -209,6 +209,7 @@ int launch_coupling_backward(int dtype, const void* z, const void* params, const
                              int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
                              int64_t gpstride, hipStream_t st) {
     const CouplingDims cd = coupling_dims(D, upper);
+    diag_count(TNF_DIAG_BWD_GENERIC);
     int W = cd.d_in > cd.d_out ? cd.d_in : cd.d_out;
     if (U > W) W = U;
     const size_t esz = dtype == TNF_F64 ? 8 : 4;

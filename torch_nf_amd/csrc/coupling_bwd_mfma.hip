@@ -530,6 +530,7 @@ int launch_coupling_backward_mfma(const float* z, const float* params, const flo
 
 int launch_coupling_backward_mfma_args(const BwdArgs& a, int D, int L, int inverse, hipStream_t st) {
     const int64_t M = a.M, N = a.N;
+    diag_count(TNF_DIAG_BWD_LAYER_FP32);
     const int64_t ntiles = (N + 15) / 16;
     int64_t bx = (ntiles + 3) / 4;
     int64_t cap = 512 / M;  // persistent grid (2 workgroups per CU): each ends with one atomic per parameter

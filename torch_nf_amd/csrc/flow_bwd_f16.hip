@@ -714,8 +714,9 @@ __global__ void __launch_bounds__(256)
 flow_bwd_reduce_kernel(const int* __restrict__ partials, const float* __restrict__ glp_part, const unsigned* __restrict__ gmax,
                        const int* __restrict__ overflow, float* __restrict__ g_params, float* __restrict__ g_fold,
                        float* __restrict__ glp_sum, int64_t nred, int nl, int P, int D, int64_t gpstride, int64_t stage,
-                       int64_t low_off, float fx) {
-    const int64_t mp = blockIdx.y;
+                       int64_t low_off, float fx, int64_t Mp) {
+    const int64_t mp = grid_m();  // parameter rows ride on grid y and z (grid_xm): any Mp
+    if (mp >= Mp) return;
     const int64_t prow = (int64_t)nl * (P + 2 * D);
     float isc = 1.f;
     {
@@ -1167,6 +1168,7 @@ int launch_coupling_backward_f16(const BwdArgs& a, int D, int L, int inverse, hi
     if (!(D == 64 || D == 32) || L < 1 || L > 3 || a.U < 1 || a.U > 16)
         return fail(TNF_EUNSUPPORTED, "coupling_backward_f16: D=%d L=%d U=%d", D, L, a.U);
     if (a.N <= 0) return TNF_OK;
+    diag_count(TNF_DIAG_BWD_LAYER_F16);
     const int64_t ntiles = (a.N + 15) / 16;
     int64_t bx = (ntiles + kLayerNW - 1) / kLayerNW;
     int64_t cap = (256 + a.M - 1) / a.M;
@@ -1234,6 +1236,8 @@ static RevWs rev_ws(int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U
     return w;
 }
 int64_t flow_train_rev_workspace(int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U) {
+    // one shared parameter row: the M * N samples are one batch (launch_flow_bwd_rev), so the partial rows do not grow with M
+    if (Mp == 1 && M > 1) return rev_ws(1, 1, M * N, D, S, L, U).total;
     return rev_ws(M, Mp, N, D, S, L, U).total;
 }
 
@@ -1244,6 +1248,7 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     constexpr int D = 2 * H;
     typedef RevImage<H, L> R;
     static_assert(R::FLOATS % 4 == 0, "image is copied in 16-byte units");
+    diag_count(TNF_DIAG_BWD_FLOW_REV);
     if (rev_image_floats(D, L) != R::FLOATS) return fail(TNF_ELAUNCH, "flow_bwd_f16: image size mismatch");
     if (rev_lds_bytes(D, S, L, U) != (2 * (int64_t)R::FLOATS + 2 * S * (int64_t)AccLayout<H, L>::INTS + (int64_t)kRevNW * kRevNScr * kScr) * 4)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: LDS size mismatch");
@@ -1285,9 +1290,9 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
         const int H_ = D / 2;
         const int P = 2 * (H_ * U + U) + (L - 1) * 2 * (U * U + U) + 2 * (U * H_ + H_);
         const int64_t prow = (int64_t)2 * S * (P + 2 * D);
-        hipLaunchKernelGGL(flow_bwd_reduce_kernel, dim3((unsigned)((prow + 255) / 256), (unsigned)Mp), dim3(256), 0, st,
+        hipLaunchKernelGGL(flow_bwd_reduce_kernel, grid_xm((prow + 255) / 256, Mp), dim3(256), 0, st,
                            reinterpret_cast<const int*>(ws + w.part), reinterpret_cast<const float*>(ws + w.glpp), gmax, overflow,
-                           g_params, gfold, glp_sum, w.nred, 2 * S, P, D, gpstride, fl.stage, fl.p_up, fx);
+                           g_params, gfold, glp_sum, w.nred, 2 * S, P, D, gpstride, fl.stage, fl.p_up, fx, Mp);
         rc = check_launch("flow_bwd_reduce");
         if (rc) return rc;
     }
@@ -1302,6 +1307,10 @@ int launch_flow_bwd_rev(const float* z0, const float* params, const float* bn_me
     if (!flow_train_rev_supported(D, S, L, U))
         return fail(TNF_EUNSUPPORTED, "flow_bwd_f16: D=%d S=%d L=%d U=%d", D, S, L, U);
     if (N <= 0) return TNF_OK;
+    if (Mp == 1 && M > 1) {  // z0 (M, N, D) and g_lp (M, N) are contiguous: M rows of one parameter row = one batch of M * N
+        N *= M;
+        M = 1;
+    }
     char* wsb = reinterpret_cast<char*>(ws);
 #define TNF_REV(HH, LL) \
     return launch_rev<HH, LL>(z0, params, bn_mean, bn_alpha, g_lp, g_z, g_params, M, Mp, N, S, U, pstride, gpstride, wsb, \

@@ -594,6 +594,7 @@ maf_gmax_kernel(const float* __restrict__ g, int64_t n, unsigned* __restrict__ o
 
 static int launch_maf_bwd_args(MafBwdArgs& a, hipStream_t st) {
     const MafBLayout wl = maf_blayout(a.D, a.L, a.U);
+    diag_count(TNF_DIAG_MAF_BWD_MFMA);
     const int nacc = maf_bwd_nacc(a.D, a.L, a.U);
     const size_t smem = maf_bwd_smem(wl, nacc);
     a.nacc = nacc;

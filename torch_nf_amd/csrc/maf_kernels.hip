@@ -368,6 +368,7 @@ int launch_maf_backward(int dtype, const void* z, const void* params, const void
                         const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N, int D, int L,
                         int U, int64_t pstride, int64_t gpstride, hipStream_t st) {
     const size_t esz = dtype == TNF_F64 ? 8 : 4;
+    diag_count(TNF_DIAG_MAF_BWD_GENERIC);
     int W;
     size_t smem;
     const int TS = maf_tile(D, U, L, esz, 1 + 2 * L + 2 + 4, N, &W, &smem);

@@ -14,6 +14,8 @@ char* err_buf();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
+void diag_count(int family);  // api.hip: process-wide launch counters behind tnf_diag_launch_count
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // The batch index m (parameter row / context) rides on grid dimensions y and z so that any M

@@ -7,6 +7,7 @@ code written against the reference (which is CPU-only) keeps working -- but the
 arithmetic always runs on the GPU; there is no CPU implementation here.
 """
 import contextlib
+import functools
 import threading
 
 import torch
@@ -15,6 +16,26 @@ from . import _lib
 from ._lib import lib, check
 
 _DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _records_options(fn):
+    """Function.forward: remember the calling thread's tnf_set_option values on the ctx ..."""
+    @functools.wraps(fn)
+    def forward(ctx, *args):
+        ctx.tnf_options = _lib.options_snapshot()
+        return fn(ctx, *args)
+    return staticmethod(forward)
+
+
+def _reenters_options(fn):
+    """... Function.backward: run under them.  autograd calls backward on its own device thread, and every option of the
+    library is thread-local: without this a kernel variant chosen around a training step (TNF_OPT_TRAIN_BWD_FP32,
+    TNF_OPT_FORCE_GENERIC, the operand precision) would govern the forward half of the step only."""
+    @functools.wraps(fn)
+    def backward(ctx, *grads):
+        with _lib.options_reentered(ctx.tnf_options):
+            return fn(ctx, *grads)
+    return staticmethod(backward)
 
 
 def _dtype_code(t):
@@ -92,14 +113,14 @@ def coupling_raw(z, params, D, L, U, upper, inverse):
 
 
 class _CouplingFn(torch.autograd.Function):
-    @staticmethod
+    @_records_options
     def forward(ctx, z, params, D, L, U, upper, inverse):
         z_out, log_det = coupling_raw(z, params, D, L, U, upper, inverse)
         ctx.save_for_backward(z, params, z_out)
         ctx.cfg = (D, L, U, upper, inverse)
         return z_out, log_det
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_z, g_ld):
         from . import grad  # backward kernels live behind the same C ABI
 
@@ -141,14 +162,14 @@ def affine_raw(z, params, D, inverse):
 
 
 class _AffineFn(torch.autograd.Function):
-    @staticmethod
+    @_records_options
     def forward(ctx, z, params, D, inverse):
         z_out, log_det = affine_raw(z, params, D, inverse)
         ctx.save_for_backward(z, params, z_out)
         ctx.cfg = (D, inverse)
         return z_out, log_det
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_z, g_ld):
         from . import grad
 
@@ -192,7 +213,7 @@ class _BnApplyFn(torch.autograd.Function):
       forward  out = (z - mean) / alpha    g_alpha = -sum g_out out / alpha - g_ld / alpha,  g_mean = -sum g_out / alpha
     (log_det = -sum log alpha in both).  The per-feature sums are a handful of torch reductions on the device."""
 
-    @staticmethod
+    @_records_options
     def forward(ctx, z, mean, alpha, inverse):
         z_out, log_det = bn_apply_raw(z, mean, alpha, inverse)
         stats_grad = mean.requires_grad or alpha.requires_grad
@@ -201,7 +222,7 @@ class _BnApplyFn(torch.autograd.Function):
         ctx.stats_grad = stats_grad
         return z_out, log_det
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_z, g_ld):
         from . import grad
 
@@ -242,13 +263,13 @@ class _BnBatchFn(torch.autograd.Function):
     without detach) back-propagates into this batch:  mean = sum z / R,  alpha = sqrt(var_b + eps)  give
     g_z += g_mean / R + g_alpha z_norm / R  (z_norm = (z - mean) / alpha)."""
 
-    @staticmethod
+    @_records_options
     def forward(ctx, z, eps):
         z_norm, log_det, mean, alpha = _bn_batch_forward_raw(z, eps)
         ctx.save_for_backward(z_norm, alpha)
         return z_norm, log_det, mean, alpha
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_zn, g_ld, g_mean, g_alpha):
         from . import grad
 
@@ -559,7 +580,7 @@ class _FlowForwardTrainFn(torch.autograd.Function):
     node for the whole stack.  Returns (z, sum_log_det, bn_mean, bn_alpha); the statistics are not differentiable
     outputs (the BatchNorm layers cache them detached, as everywhere in this package)."""
 
-    @staticmethod
+    @_records_options
     def forward(ctx, omega, params, D, S, L, U, eps):
         dev = _lib.require_device()
         oc = _stage(omega.detach(), dev)
@@ -583,7 +604,7 @@ class _FlowForwardTrainFn(torch.autograd.Function):
         ctx.mark_non_differentiable(mean, alpha)
         return z, sld, mean, alpha
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_z, g_sld, _gm, _ga):
         oc, pc, states, folds, mean, alpha = ctx.saved_tensors
         D, S, L, U, pstride, o_home, p_home, p_shape = ctx.cfg
@@ -614,7 +635,7 @@ def flow_train_supported(M, Mp, N, D, S, L, U):
 
 
 class _FlowLogProbFn(torch.autograd.Function):
-    @staticmethod
+    @_records_options
     def forward(ctx, z, params, bn_mean, bn_alpha, D, S, L, U):
         dev = _lib.require_device()
         zc = _stage(z.detach(), dev)
@@ -633,7 +654,7 @@ class _FlowLogProbFn(torch.autograd.Function):
         ctx.cfg = (D, S, L, U, pstride, z.device, params.device, tuple(params.shape))
         return lp if z.device == dev else lp.to(z.device)
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_lp):
         zc, pc, mean_c, alpha_c, states = ctx.saved_tensors
         D, S, L, U, pstride, z_home, p_home, p_shape = ctx.cfg
@@ -683,7 +704,7 @@ class _FlowLogProbRevFn(torch.autograd.Function):
     overflow_fallbacks = 0  # "host" mode: how often the fp32 pair had to take over (diagnostic)
     last_overflow_flag = None  # "device" mode: the flag tensor of the latest backward (diagnostic, read it after a sync)
 
-    @staticmethod
+    @_records_options
     def forward(ctx, z, params, bn_mean, bn_alpha, D, S, L, U):
         dev = _lib.require_device()
         zc = _stage(z.detach(), dev)
@@ -700,7 +721,7 @@ class _FlowLogProbRevFn(torch.autograd.Function):
         ctx.cfg = (D, S, L, U, pstride, z.device, params.device, tuple(params.shape))
         return lp if z.device == dev else lp.to(z.device)
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_lp):
         z0, pc, mean_c, alpha_c, zc = ctx.saved_tensors
         D, S, L, U, pstride, z_home, p_home, p_shape = ctx.cfg
@@ -760,13 +781,14 @@ def _flow_log_prob_grad_fp32(zc, pc, pstride, mean_c, alpha_c, g, D, S, L, U, p_
                                         _lib.stream_ptr()))
     gz = torch.empty_like(zc)
     gp = torch.zeros(p_shape, dtype=torch.float32, device=dev)
+    before = _lib.options_snapshot()
     check(lib.tnf_set_option(_lib.OPT_TRAIN_BWD_FP32, 1))
     try:
         check(lib.tnf_flow_log_prob_bwd_f32(zc.data_ptr(), states.data_ptr(), pc.data_ptr(), mean_c.data_ptr(),
                                             alpha_c.data_ptr(), g.data_ptr(), gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, S,
                                             L, U, pstride, gp.shape[1], ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
     finally:
-        check(lib.tnf_set_option(_lib.OPT_TRAIN_BWD_FP32, 0))
+        check(lib.tnf_set_option(_lib.OPT_TRAIN_BWD_FP32, before[_lib._OPTION_KEYS.index(_lib.OPT_TRAIN_BWD_FP32)]))
     return (gz if want_gz else None), gp
 
 
@@ -833,7 +855,7 @@ class _MafFn(torch.autograd.Function):
     exactly by D sweeps of  v <- v + e^alpha (g_x - K_z(v, -g_ld))  (the error moves strictly along the
     autoregressive order), and then  g_omega = v,  g_theta = -K_theta(v, -g_ld)."""
 
-    @staticmethod
+    @_records_options
     def forward(ctx, z, params, masks, D, L, U, inverse):
         z_out, log_det = maf_raw(z, params, masks, D, L, U, inverse)
         if inverse:
@@ -844,7 +866,7 @@ class _MafFn(torch.autograd.Function):
         ctx.prec = current_operand_precision()
         return z_out, log_det
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_z, g_ld):
         with operand_precision(ctx.prec):  # autograd's thread: re-enter the forward's operand precision
             return _MafFn._backward(ctx, g_z, g_ld)
@@ -910,14 +932,14 @@ def to_interval_raw(z, consts, inverse):
 
 
 class _ToIntervalFn(torch.autograd.Function):
-    @staticmethod
+    @_records_options
     def forward(ctx, z, consts, inverse):
         out = to_interval_raw(z, consts, inverse)
         ctx.save_for_backward(z, consts)
         ctx.inverse = inverse
         return out
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_z, g_ld):
         z, consts = ctx.saved_tensors
         dev = _lib.require_device()
@@ -956,14 +978,14 @@ def to_simplex_raw(z, D_attr):
 
 
 class _ToSimplexFn(torch.autograd.Function):
-    @staticmethod
+    @_records_options
     def forward(ctx, z, D_attr):
         out = to_simplex_raw(z, D_attr)
         ctx.save_for_backward(z)
         ctx.D_attr = D_attr
         return out
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_z, g_ld):
         (z,) = ctx.saved_tensors
         dev = _lib.require_device()
@@ -1040,7 +1062,7 @@ class _CondFlowLogProbFn(torch.autograd.Function):
     activations (6 KB per context at D = 64), tnf_cond_flow_log_prob_bwd_f32 returns the gradients of
     param_net's last Linear and of its input; torch autograd carries on through the rest of param_net."""
 
-    @staticmethod
+    @_records_options
     def forward(ctx, z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U):
         dev = _lib.require_device()
         M, H = h.shape
@@ -1064,7 +1086,7 @@ class _CondFlowLogProbFn(torch.autograd.Function):
         ctx.homes = (z.device, h.device, weight.device, bias.device)
         return lp
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_lp):
         hc, wc, bc, mean, alpha, acts = ctx.saved_tensors
         M, H, Hp, D, S, L, U = ctx.cfg
@@ -1147,7 +1169,7 @@ class _ArFlowLogProbFn(torch.autograd.Function):
     (tnf_ar_flow_log_prob_bwd_f32: ToInterval^-1, the folded Affine / BatchNorm, MAF recompute and backward,
     base density) writing the gradient of every parameter slice into one buffer."""
 
-    @staticmethod
+    @_records_options
     def forward(ctx, z, params, masks, bn_mean, bn_alpha, interval_consts, D, L, U):
         lp, _, _ = ar_flow_log_prob_raw(z, params, masks, bn_mean, bn_alpha, D, L, U, interval_consts=interval_consts)
         dev = _lib.require_device()
@@ -1160,7 +1182,7 @@ class _ArFlowLogProbFn(torch.autograd.Function):
         ctx.prec = current_operand_precision()
         return lp
 
-    @staticmethod
+    @_reenters_options
     def backward(ctx, g_lp):
         zc, pc, mk, mean, alpha = ctx.saved_tensors
         D, L, U, pstride, p_home, p_shape = ctx.cfg
