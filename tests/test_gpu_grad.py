@@ -571,12 +571,11 @@ def test_bn_statistics_stay_in_graph(tnf, oracle, arch, D, S, home):
 
     loss_ref, g_ref = oracle_loss(False)
     _, g_det = oracle_loss(True)
-    # home = "cpu": a caller of the reference -- host tensors in, host tensors out; the cached statistics then live on
-    # the host WITH their graph and the staged device copies must stay differentiable
+    # home = "cpu": a caller of the reference -- host tensors in, host tensors out (NormFlow stages them once, so its
+    # BatchNorm layers cache device statistics; the stand-alone bijector case is the test below)
     p = p0.to(home).requires_grad_()
     z, lq = nf._forward_from(omega, p, freeze_bn=False)
     assert all(b.get_last_alpha().requires_grad for b in nf._bn_layers())
-    assert all(b.get_last_alpha().device.type == home for b in nf._bn_layers())
     lp = nf.log_prob(z_eval.to(home), p)
     loss = lq.mean() + 0.5 * lp.double().mean() + 0.1 * (z.double() ** 2).mean()
     loss.backward()
@@ -643,3 +642,35 @@ def test_cde_fused_conditioner_respects_statistics_in_graph(tnf, oracle):
     for b in nf._bn_layers():
         b.set_last_stats(b.get_last_mean(), b.get_last_alpha())
     assert cde._fused_conditioner_ok(z_eval.cuda(), xd)
+
+
+@pytest.mark.parametrize("inverse", [True, False])
+def test_bn_cached_statistics_keep_their_graph_for_host_callers(tnf, inverse):
+    """A BatchNorm bijector called with HOST tensors (every caller of the reference): the batch-mode forward caches
+    mean / alpha on the host with their graph (bijectors.py:414-415), and a later frozen forward / inverse in the same
+    graph must differentiate through them -- the staged device copies may not be detached.  Against plain torch."""
+    D, N = 6, 50
+    rng = np.random.RandomState(11)
+    z1 = torch.tensor(rng.normal(0.5, 2.0, (2, N, D))).float()
+    z2 = torch.tensor(rng.normal(0, 1, (2, 9, D))).float()
+    w = torch.tensor(rng.normal(0, 1, (2, 9, D))).float()
+
+    def ref():
+        a = z1.clone().requires_grad_()
+        flat = a.reshape(-1, D)
+        mean = flat.mean(0)
+        alpha = torch.sqrt(flat.var(0, unbiased=False) + 1e-5)
+        out = z2 * alpha + mean if inverse else (z2 - mean) / alpha
+        ld = -torch.log(alpha).sum()
+        ((out * w).sum() + 0.3 * ld + (((flat - mean) / alpha) ** 2 * 0.01).sum()).backward()
+        return a.grad
+
+    bn = tnf.BatchNorm(D)
+    a = z1.clone().requires_grad_()
+    zn, _ = bn(a)                                  # batch mode, host tensor in
+    assert bn.get_last_alpha().device.type == "cpu" and bn.get_last_alpha().requires_grad
+    out, ld = bn.inverse_and_log_det(z2) if inverse else bn(z2, use_last=True)
+    assert out.device.type == "cpu"
+    ((out * w).sum() + 0.3 * ld + (zn ** 2 * 0.01).sum()).backward()
+    g_ref = ref()
+    torch.testing.assert_close(a.grad, g_ref, rtol=2e-4, atol=2e-5 * float(g_ref.abs().max()))
