@@ -69,6 +69,8 @@ enum {
     TNF_OPT_LAYER_VARIANT = 3, /* tuning: launch geometry of the per-layer kernel */
     TNF_OPT_COND_VARIANT = 4,  /* tuning: contexts per wave / waves per workgroup of the conditional-flow kernel */
     TNF_OPT_TRAIN_BWD_FP32 = 5, /* != 0: tnf_flow_forward_train_bwd_f32 uses the fp32-MFMA layer backward kernel */
+    TNF_OPT_REV_VARIANT = 7,    /* whole-flow training backward: 0 (default) flow_bwd_f16_kernel, 1 the magic-number
+                                 * form of flow_bwd_pair.h (an experiment that did not pay: DESIGN.md 3.11.1) */
     TNF_OPT_OPERAND_PREC = 6    /* 0 (default): fp32-accurate operands.  1: tnf_flow_log_prob_f32 and
                                  * tnf_flow_log_prob_fwd_rev_f32 round every conditioner operand to bf16 (one MFMA per
                                  * contraction) -- the precision experiment of BASELINE configs[4], not a parity path */

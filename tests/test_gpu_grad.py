@@ -674,3 +674,39 @@ def test_bn_cached_statistics_keep_their_graph_for_host_callers(tnf, inverse):
     ((out * w).sum() + 0.3 * ld + (zn ** 2 * 0.01).sum()).backward()
     g_ref = ref()
     torch.testing.assert_close(a.grad, g_ref, rtol=2e-4, atol=2e-5 * float(g_ref.abs().max()))
+
+
+@pytest.mark.parametrize("D,S,L,U,M,Mp,N", [(64, 4, 2, 15, 1, 1, 300), (64, 2, 2, 16, 2, 2, 70), (32, 2, 3, 15, 3, 1, 40)])
+def test_flow_reversible_backward_magic_form(tnf, oracle, D, S, L, U, M, Mp, N):
+    """TNF_OPT_REV_VARIANT 1 -- the round-3 experiment of flow_bwd_pair.h (magic-number accumulation, sigmoid operands,
+    db - 2 G formed by the reduction) -- against torch autograd over the oracle and against the default kernel, and bit
+    for bit reproducible like it.  It is not the default; this keeps it honest."""
+    rng = np.random.RandomState(D + N)
+    nf = tnf.NormFlow(D, True, "coupling", S, L, U)
+    p0 = torch.tensor(rng.normal(0, 0.1, (Mp, nf.D_params))).float()
+    z0 = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+    w = torch.tensor(rng.uniform(0.5, 1.5, (M, N))).float()
+    stats = []
+    for b in nf._bn_layers():
+        m_, a_ = torch.tensor(rng.normal(0, 0.3, D)).float(), torch.tensor(np.exp(rng.normal(0, 0.2, D))).float()
+        b.set_last_stats(m_, a_)
+        stats.append((m_, a_))
+    pr, zr = p0.clone().requires_grad_(), z0.clone().requires_grad_()
+    (oracle.flow_log_prob(zr, pr, D, S, L, U, stats) * w).sum().backward()
+    lib = tnf._lib.lib
+    res = []
+    for variant in (1, 0, 1):
+        before = lib.tnf_diag_launch_count(tnf._lib.DIAG_BWD_FLOW_REV)
+        tnf._lib.check(lib.tnf_set_option(tnf._lib.OPT_REV_VARIANT, variant))
+        try:
+            p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
+            (nf.log_prob(z, p) * w.cuda()).sum().backward()
+            res.append((p.grad.cpu(), z.grad.cpu()))
+        finally:
+            lib.tnf_set_option(tnf._lib.OPT_REV_VARIANT, 0)
+        assert lib.tnf_diag_launch_count(tnf._lib.DIAG_BWD_FLOW_REV) == before + 1
+    sp, sz = float(pr.grad.abs().max()), float(zr.grad.abs().max())
+    for gp, gz in res:
+        assert float((gp - pr.grad).abs().max()) <= 1e-4 * sp
+        assert float((gz - zr.grad).abs().max()) <= 2e-5 * sz
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])

@@ -18,6 +18,7 @@ LD_STORE, LD_ADD, LD_SUB = 0, 1, -1
 FUSE_AUTO, FUSE_LAYER, FUSE_FLOW = 0, 1, 2
 OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT, OPT_COND_VARIANT, OPT_TRAIN_BWD_FP32 = 1, 2, 3, 4, 5
 OPT_OPERAND_PREC = 6
+OPT_REV_VARIANT = 7
 EUNSUPPORTED = -2
 DIAG_BWD_LAYER_FP32, DIAG_BWD_LAYER_F16, DIAG_BWD_GENERIC, DIAG_BWD_FLOW_REV = 0, 1, 2, 3
 DIAG_MAF_BWD_MFMA, DIAG_MAF_BWD_GENERIC, DIAG_BWD_WIDE = 4, 5, 6
@@ -150,7 +151,7 @@ def check(rc):
 
 
 _OPTION_KEYS = (OPT_FORCE_GENERIC, OPT_FLOW_VARIANT, OPT_LAYER_VARIANT, OPT_COND_VARIANT, OPT_TRAIN_BWD_FP32,
-                OPT_OPERAND_PREC)
+                OPT_OPERAND_PREC, OPT_REV_VARIANT)
 
 
 def options_snapshot():

@@ -141,6 +141,11 @@ int tnf_set_option(int32_t key, int32_t value) {
         g_cond_variant = value;
         return TNF_OK;
     }
+    if (key == TNF_OPT_REV_VARIANT) {
+        if (value != 0 && value != 1) return fail(TNF_EINVAL, "tnf_set_option: reversible-backward variant %d", value);
+        g_rev_variant = value;
+        return TNF_OK;
+    }
     return fail(TNF_EINVAL, "tnf_set_option: unknown key %d", key);
 }
 
@@ -158,6 +163,7 @@ int tnf_get_option(int32_t key, int32_t* value) {
         case TNF_OPT_COND_VARIANT: *value = g_cond_variant; return TNF_OK;
         case TNF_OPT_TRAIN_BWD_FP32: *value = g_train_bwd_fp32; return TNF_OK;
         case TNF_OPT_OPERAND_PREC: *value = g_operand_prec; return TNF_OK;
+        case TNF_OPT_REV_VARIANT: *value = g_rev_variant; return TNF_OK;
     }
     return fail(TNF_EINVAL, "tnf_get_option: unknown key %d", key);
 }

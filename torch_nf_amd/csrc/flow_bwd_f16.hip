@@ -63,8 +63,10 @@ struct RevImage {
     static constexpr int FLOATS = C_OFF + 4 * D;
 };
 
+// hscale multiplies the transposed HIDDEN and OUTPUT weights (the operands whose product is followed by a tanh'): 1 for
+// the kernels that form tanh' = 1 - h^2, 4 for the pair kernel, whose tanh' is 4 r (1 - r) with the 4 carried here.
 template <int H, int L>
-__device__ __forceinline__ void build_b16_image(float* img, const float* __restrict__ p, int U, int lane) {
+__device__ __forceinline__ void build_b16_image(float* img, const float* __restrict__ p, int U, int lane, float hscale = 1.f) {
     typedef B16Image<H, L> Img;
     constexpr int HT = Img::HT;
     const int r = lane & 15, q = lane >> 4;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void build_b16_image(float* img, const float* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ki = r, ko = 4 * q + j;
-                v[j] = ld_sel(w[net], ki * U + ko, ki < U && ko < U);
+                v[j] = hscale * ld_sel(w[net], ki * U + ko, ki < U && ko < U);
             }
             u4 o;
             split2(v[0], v[1], o[0], o[2]);
@@ -115,7 +117,7 @@ __device__ __forceinline__ void build_b16_image(float* img, const float* __restr
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int o = 16 * (i >> 2) + 4 * q + (i & 3);
-                    v[i] = ld_sel(w[net], r * H + o, r < U);
+                    v[i] = hscale * ld_sel(w[net], r * H + o, r < U);
                 }
                 u4 hi, lo;
 #pragma unroll
@@ -125,7 +127,7 @@ __device__ __forceinline__ void build_b16_image(float* img, const float* __restr
             } else {
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ld_sel(w[net], r * H + 4 * q + j, r < U);
+                for (int j = 0; j < 4; ++j) v[j] = hscale * ld_sel(w[net], r * H + 4 * q + j, r < U);
                 u4 o;
                 split2(v[0], v[1], o[0], o[2]);
                 split2(v[2], v[3], o[1], o[3]);
@@ -140,7 +142,7 @@ template <int H, int L>
 __global__ void __launch_bounds__(64)
 flow_rev_images_kernel(const float* __restrict__ params, const float* __restrict__ bn_mean,
                        const float* __restrict__ bn_alpha, float* __restrict__ rimg, int S, int U, int64_t pstride,
-                       int64_t Mp) {
+                       int64_t Mp, float hscale) {
     typedef RevImage<H, L> R;
     constexpr int D = 2 * H;
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -151,7 +153,7 @@ flow_rev_images_kernel(const float* __restrict__ params, const float* __restrict
     const float* p = prow + (c >> 1) * fl.stage + ((c & 1) ? fl.p_up : 0);
     float* img = rimg + (m * 2 * S + c) * (int64_t)R::FLOATS;
     build_f16_image<H, L>(img + R::F_OFF, p, U, lane);
-    build_b16_image<H, L>(img + R::B_OFF, p, U, lane);
+    build_b16_image<H, L>(img + R::B_OFF, p, U, lane, hscale);
     float* fc = img + R::C_OFF;
     for (int d = lane; d < D; d += 64) {  // the inverse-pass fold of flow_fold_kernel (coupling_mfma.hip)
         const float alpha = bn_alpha[c * D + d], mu = bn_mean[c * D + d];
@@ -714,7 +716,7 @@ __global__ void __launch_bounds__(256)
 flow_bwd_reduce_kernel(const int* __restrict__ partials, const float* __restrict__ glp_part, const unsigned* __restrict__ gmax,
                        const int* __restrict__ overflow, float* __restrict__ g_params, float* __restrict__ g_fold,
                        float* __restrict__ glp_sum, int64_t nred, int nl, int P, int D, int64_t gpstride, int64_t stage,
-                       int64_t low_off, float fx, int64_t Mp) {
+                       int64_t low_off, float fx, int64_t Mp, int tanh_pair, int U, int L) {
     const int64_t mp = grid_m();  // parameter rows ride on grid y and z (grid_xm): any Mp
     if (mp >= Mp) return;
     const int64_t prow = (int64_t)nl * (P + 2 * D);
@@ -745,6 +747,36 @@ flow_bwd_reduce_kernel(const int* __restrict__ partials, const float* __restrict
         for (; b < nred; ++b) acc += (long long)src[b * prow + i];
         const int c = (int)(i / (P + 2 * D));
         const int k = (int)(i - (int64_t)c * (P + 2 * D));
+        if (tanh_pair && k < P) {
+            // the rows of flow_bwd_pair_kernel: a weight behind a tanh holds G = sum_s r_k d_o; its gradient is
+            // db_o - 2 G with db_o the bias entry of the same MLP layer and net (flow_bwd_pair.h)
+            const int H = D / 2;
+            int kk = k - (2 * H * U + 2 * U), bias = -1;
+            if (kk >= 0) {
+                const int hs = 2 * U * U + 2 * U;
+                if (kk < (L - 1) * hs) {
+                    const int l = kk / hs, r = kk - l * hs;
+                    if (r < 2 * U * U) bias = 2 * H * U + 2 * U + l * hs + 2 * U * U + (r / (U * U)) * U + r % U;
+                } else {
+                    kk -= (L - 1) * hs;
+                    if (kk < 2 * U * H) bias = 2 * H * U + 2 * U + (L - 1) * hs + 2 * U * H + (kk / (U * H)) * H + kk % H;
+                }
+            }
+            if (bias >= 0) {
+                long long db = 0;
+                const int* bsrc = src + (int64_t)c * (P + 2 * D) + bias;
+                int64_t bb = 0;
+                for (; bb + 8 <= nred; bb += 8) {
+                    int v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = bsrc[(bb + u) * prow];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) db += (long long)v[u];
+                }
+                for (; bb < nred; ++bb) db += (long long)bsrc[bb * prow];
+                acc = db - 2 * acc;
+            }
+        }
         const float v = (float)acc * unfx + poison;
         if (k < P) g_params[mp * gpstride + (c >> 1) * stage + ((c & 1) ? low_off : 0) + k] += v;
         else if (c & 1) g_fold[(mp * nl + c) * 2 * D + (k - P)] += v;
@@ -763,15 +795,16 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
     constexpr int D = 2 * H;
     constexpr int HT = (H + 15) / 16;
     constexpr int RU4 = R::FLOATS / 4;
-    constexpr int NPF = (RU4 + NW * 64 - 1) / (NW * 64);
+    constexpr int SLOT = (R::FLOATS + 255) & ~255;  // ring slot: whole 1-KB LDS-DMA pieces
+    constexpr int NPIECE = SLOT / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nl = 2 * a.S;
     const int U = a.U;
     typedef AccLayout<H, L> A_;
     constexpr int ACC = A_::INTS;
-    float* ring = lds;                          // [2][R::FLOATS]
-    int* accb = reinterpret_cast<int*>(lds + 2 * R::FLOATS);  // [nl][ACC] fixed point
-    float* scr = lds + 2 * R::FLOATS + nl * ACC;              // [NW][2][kScr]
+    float* ring = lds;                          // [2][SLOT]
+    int* accb = reinterpret_cast<int*>(lds + 2 * SLOT);  // [nl][ACC] fixed point
+    float* scr = lds + 2 * SLOT + nl * ACC;              // [NW][kRevNScr][kScr]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, q = lane >> 4;
@@ -782,8 +815,20 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
     float* scrB = scrA + (kRevNScr - 1) * kScr;
     const u4* isrc = reinterpret_cast<const u4*>(a.rimg + mp * (int64_t)nl * R::FLOATS);
 
+    // layer image c -> ring slot by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, no staging registers --
+    // round 2 prefetched the next image through 28 VGPRs per lane); a piece's tail beyond the image re-reads its last
+    // 16 bytes into the slot's padding
+    typedef __attribute__((address_space(3))) void lds_void_;
+    auto fetch = [&](int c, float* slot) {
+        const u4* src = isrc + (int64_t)c * RU4;
+        for (int i = wave; i < NPIECE; i += NW) {
+            const int idx = i * 64 + lane;
+            __builtin_amdgcn_global_load_lds(src + (idx < RU4 ? idx : RU4 - 1), (lds_void_*)(slot + i * 256), 16, 0, 0);
+        }
+    };
+    fetch(0, ring);
     for (int i = threadIdx.x; i < nl * ACC; i += NW * 64) accb[i] = 0;
-    for (int i = threadIdx.x; i < RU4; i += NW * 64) reinterpret_cast<u4*>(ring)[i] = isrc[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // power-of-two scale that brings max |g_lp| into [1, 2)
     float sc = 1.f, isc = 1.f;
     {
@@ -834,18 +879,9 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
         const float gl = -glp;  // log_prob = base - sum of the layers' log-dets
 
         for (int c = 0; c < nl; ++c, ++step) {
-            const float* img = ring + (step & 1) * R::FLOATS;
-            float* nxt = ring + ((step + 1) & 1) * R::FLOATS;
+            const float* img = ring + (step & 1) * SLOT;
             const bool more = (int64_t)step + 1 < nsteps;
-            u4 pf[NPF];
-            if (more) {
-                const u4* src = isrc + (int64_t)((c + 1 == nl) ? 0 : c + 1) * RU4;
-#pragma unroll
-                for (int i = 0; i < NPF; ++i) {
-                    const int idx = threadIdx.x + i * NW * 64;
-                    pf[i] = src[idx < RU4 ? idx : 0];
-                }
-            }
+            if (more) fetch((c + 1 == nl) ? 0 : c + 1, ring + ((step + 1) & 1) * SLOT);
             int* acc = accb + c * ACC;
             const float* fc = img + R::C_OFF;
             if ((c & 1) == 0) {  // RealNVP(upper): conditioner = low half
@@ -859,13 +895,7 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, 0, lo, glo);
                 unfold_half<H, true>(fc, acc + A_::o_fold, fa, scrA, scrB, lane, H, hi, ghi);
             }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < NPF; ++i) {
-                    const int idx = threadIdx.x + i * NW * 64;
-                    if (idx < RU4) reinterpret_cast<u4*>(nxt)[idx] = pf[i];
-                }
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next image have landed
             __syncthreads();
         }
         if (gzb && row_ok) {
@@ -927,6 +957,10 @@ flow_bwd_f16_kernel(FlowBwdArgs a) {
         }
     }
 }
+
+}  // namespace tnf
+#include "flow_bwd_pair.h"
+namespace tnf {
 
 // ---------------------------------------------------------------------------
 // One forward-direction coupling layer backwards with its INPUT saved (the training-mode chain of coupling_mfma.hip:
@@ -1198,23 +1232,39 @@ static int64_t rev_image_floats(int D, int L) {
 
 
 
-static int64_t rev_lds_bytes(int D, int S, int L, int U) {
+static int64_t rev_acc_ints(int D, int L) {
     const int H = D / 2;
     const int64_t HT = H / 16;
-    const int64_t ACC = (2 * HT * 256 + 32 + (int64_t)(L - 1) * (2 * 256 + 32) + 2 * HT * 256 + 2 * H + 4 * H + 3) & ~3LL;
-    (void)U;
-    return (2 * rev_image_floats(D, L) + 2 * S * ACC + (int64_t)kRevNW * kRevNScr * kScr) * 4;
+    return (2 * HT * 256 + 32 + (int64_t)(L - 1) * (2 * 256 + 32) + 2 * HT * 256 + 2 * H + 4 * H + 3) & ~3LL;
 }
+static int64_t rev_lds_bytes(int D, int S, int L, int U) {  // the round-2 kernel (one tile per wave)
+    (void)U;
+    const int64_t slot = (rev_image_floats(D, L) + 255) & ~255LL;  // whole 1-KB LDS-DMA pieces
+    return (2 * slot + 2 * S * rev_acc_ints(D, L) + (int64_t)kRevNW * kRevNScr * kScr) * 4;
+}
+static int64_t pair_lds_bytes(int D, int S, int L) {  // the pair kernel (PairLds<H, L>::floats)
+    const int64_t slot = (rev_image_floats(D, L) + 255) & ~255LL;
+    return (2 * slot + 2 * S * rev_acc_ints(D, L) + (int64_t)kPairNW * kPairNT * kScr) * 4;
+}
+
+// TNF_OPT_REV_VARIANT: 0 = flow_bwd_f16_kernel (default), 1 = the magic-number form of flow_bwd_pair.h (measured
+// slower or equal on every shape tried; kept selectable as the evidence)
+thread_local int g_rev_variant = 0;
 
 int flow_train_rev_supported(int D, int S, int L, int U) {
     if (!(D == 64 || D == 32) || L < 1 || L > 3 || U < 1 || U > 16 || S < 1) return 0;
     return rev_lds_bytes(D, S, L, U) <= 160 * 1024 ? 1 : 0;
 }
+static bool rev_use_pair(int D, int S, int L, int U) {
+    (void)U;
+    return g_rev_variant == 1 && pair_lds_bytes(D, S, L) <= 160 * 1024;
+}
 
-// launch geometry of the backward kernel (shared with the workspace size: the partial rows depend on it)
-static int64_t rev_blocks_x(int64_t M, int64_t N) {
-    const int64_t ntiles = (N + 15) / 16;
-    int64_t bx = (ntiles + kRevNW - 1) / kRevNW;
+// launch geometry of the backward kernels (shared with the workspace size: the partial rows depend on it)
+static int64_t rev_blocks_x(int64_t M, int64_t N, bool pair) {
+    const int64_t units = pair ? (N + 16 * kPairNT - 1) / (16 * kPairNT) : (N + 15) / 16;  // groups of kPairNT tiles / tiles
+    const int nw = pair ? kPairNW : kRevNW;
+    int64_t bx = (units + nw - 1) / nw;
     const int64_t cap = (256 + M - 1) / M;
     return bx > cap ? cap : (bx < 1 ? 1 : bx);
 }
@@ -1227,7 +1277,8 @@ static RevWs rev_ws(int64_t M, int64_t Mp, int64_t N, int D, int S, int L, int U
     RevWs w;
     const int H = D / 2;
     const int64_t P = 2 * (H * U + U) + (int64_t)(L - 1) * 2 * (U * U + U) + 2 * (U * H + H);
-    w.nred = (Mp == 1 ? M : 1) * rev_blocks_x(M, N > 0 ? N : 1);  // workgroups that add into one gradient row
+    const int64_t bx0 = rev_blocks_x(M, N > 0 ? N : 1, false), bx1 = rev_blocks_x(M, N > 0 ? N : 1, true);
+    w.nred = (Mp == 1 ? M : 1) * (bx0 > bx1 ? bx0 : bx1);  // workgroups that add into one gradient row (either kernel)
     w.rimg = 0;
     w.gfold = ((Mp * 2 * S * rev_image_floats(D, L) * 4 + 255) / 256) * 256;
     w.glpp = w.gfold + ((Mp * 2 * S * 2 * D + Mp + 2) * 4 + 255) / 256 * 256;
@@ -1250,8 +1301,10 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     static_assert(R::FLOATS % 4 == 0, "image is copied in 16-byte units");
     diag_count(TNF_DIAG_BWD_FLOW_REV);
     if (rev_image_floats(D, L) != R::FLOATS) return fail(TNF_ELAUNCH, "flow_bwd_f16: image size mismatch");
-    if (rev_lds_bytes(D, S, L, U) != (2 * (int64_t)R::FLOATS + 2 * S * (int64_t)AccLayout<H, L>::INTS + (int64_t)kRevNW * kRevNScr * kScr) * 4)
+    if (rev_lds_bytes(D, S, L, U) != (2 * (int64_t)PairLds<H, L>::SLOT + 2 * S * (int64_t)AccLayout<H, L>::INTS + (int64_t)kRevNW * kRevNScr * kScr) * 4 ||
+        pair_lds_bytes(D, S, L) != PairLds<H, L>::floats(2 * S) * 4)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: LDS size mismatch");
+    const bool pair = rev_use_pair(D, S, L, U);
     const RevWs w = rev_ws(M, Mp, N, D, S, L, U);
     float* rimg = reinterpret_cast<float*>(ws + w.rimg);
     float* gfold = reinterpret_cast<float*>(ws + w.gfold);
@@ -1261,7 +1314,7 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
     if (hipMemsetAsync(gfold, 0, (size_t)(Mp * 2 * S * 2 * D + Mp + 2) * sizeof(float), st) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_bwd_f16: memset failed");
     hipLaunchKernelGGL((flow_rev_images_kernel<H, L>), grid_xm(2 * S, Mp), dim3(64), 0, st, params, bn_mean, bn_alpha,
-                       rimg, S, U, pstride, Mp);
+                       rimg, S, U, pstride, Mp, pair ? 4.f : 1.f);
     {
         const int64_t n = M * N;
         int64_t blocks = (n + 255) / 256;
@@ -1269,21 +1322,34 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
         hipLaunchKernelGGL(flow_gmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g_lp, n, gmax, (const int*)nullptr);
     }
     const FlowLayout fl = flow_layout(D, S, L, U);
-    const size_t smem = (size_t)rev_lds_bytes(D, S, L, U);
-    auto kern = U <= 15 ? flow_bwd_f16_kernel<H, L, kRevNW, true> : flow_bwd_f16_kernel<H, L, kRevNW, false>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-        return fail(TNF_ELAUNCH, "flow_bwd_f16: cannot reserve %zu B of LDS", smem);
-    const int64_t ntiles = (N + 15) / 16;
-    const int64_t bx = rev_blocks_x(M, N);
-    // an accumulator receives iters * NW terms per workgroup; allow 2^13 per term inside the int32 range
-    const int64_t adds = ((ntiles + bx * kRevNW - 1) / (bx * kRevNW)) * kRevNW;
+    const int64_t bx = rev_blocks_x(M, N, pair);
+    const int nw = pair ? kPairNW : kRevNW;
+    const int64_t units = pair ? (N + 16 * kPairNT - 1) / (16 * kPairNT) : (N + 15) / 16;
+    // an accumulator receives iters * NW terms per workgroup; allow 2^13 per term inside the int32 range (2^11 in the
+    // round-3 kernel, whose magic-number sums hold 22 bits per term and round three times per term instead of once)
+    const int64_t adds = ((units + bx * nw - 1) / (bx * nw)) * nw;
     int fbits = 31 - 13;
     for (int64_t v = 1; v < adds; v <<= 1) --fbits;
+    if (pair && fbits > kPairMaxFbits) fbits = kPairMaxFbits;
     if (fbits < 0) fbits = 0;
     const float fx = ldexpf(1.f, fbits);
     FlowBwdArgs a{z0, g_lp, rimg, gmax, g_z, g_params, gfold, glp_sum, M, Mp, N, gpstride, fl.stage, fl.p_up, S, U, fx,
                   reinterpret_cast<int*>(ws + w.part), reinterpret_cast<float*>(ws + w.glpp), overflow};
-    hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(kRevNW * 64), smem, st, a);
+    // the partial rows are indexed by this launch's own grid; the reduction reads as many
+    const int64_t nred = (Mp == 1 ? M : 1) * bx;
+    if (pair) {
+        const size_t smem = (size_t)pair_lds_bytes(D, S, L);
+        auto kern = U <= 15 ? flow_bwd_pair_kernel<H, L, true> : flow_bwd_pair_kernel<H, L, false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return fail(TNF_ELAUNCH, "flow_bwd_pair: cannot reserve %zu B of LDS", smem);
+        hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(kPairNW * 64), smem, st, a);
+    } else {
+        const size_t smem = (size_t)rev_lds_bytes(D, S, L, U);
+        auto kern = U <= 15 ? flow_bwd_f16_kernel<H, L, kRevNW, true> : flow_bwd_f16_kernel<H, L, kRevNW, false>;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return fail(TNF_ELAUNCH, "flow_bwd_f16: cannot reserve %zu B of LDS", smem);
+        hipLaunchKernelGGL(kern, grid_xm(bx, M), dim3(kRevNW * 64), smem, st, a);
+    }
     int rc = check_launch("flow_bwd_f16");
     if (rc) return rc;
     {
@@ -1292,7 +1358,7 @@ static int launch_rev(const float* z0, const float* params, const float* bn_mean
         const int64_t prow = (int64_t)2 * S * (P + 2 * D);
         hipLaunchKernelGGL(flow_bwd_reduce_kernel, grid_xm((prow + 255) / 256, Mp), dim3(256), 0, st,
                            reinterpret_cast<const int*>(ws + w.part), reinterpret_cast<const float*>(ws + w.glpp), gmax, overflow,
-                           g_params, gfold, glp_sum, w.nred, 2 * S, P, D, gpstride, fl.stage, fl.p_up, fx, Mp);
+                           g_params, gfold, glp_sum, nred, 2 * S, P, D, gpstride, fl.stage, fl.p_up, fx, Mp, pair ? 1 : 0, U, L);
         rc = check_launch("flow_bwd_reduce");
         if (rc) return rc;
     }

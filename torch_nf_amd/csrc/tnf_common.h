@@ -72,6 +72,7 @@ extern thread_local int g_layer_variant;  // coupling_mfma.hip
 extern thread_local int g_train_bwd_fp32; // coupling_mfma.hip
 extern thread_local int g_cond_variant;   // cond_flow.hip
 extern thread_local const int* g_launch_gate;  // api.hip: tnf_set_launch_gate
+extern thread_local int g_rev_variant;    // flow_bwd_f16.hip
 extern thread_local int g_operand_prec;   // api.hip: 0 = fp32-accurate split-f16 operands, 1 = bf16 operands (experiment)
 
 // ---- kernels implemented in the .hip files ----------------------------------
