@@ -186,6 +186,29 @@ int tnf_bn_batch_backward_f32(const float* z_norm, const float* g_z_out, const f
                               const float* alpha, float* g_z, int64_t rows, int32_t D, void* workspace,
                               int64_t workspace_bytes, void* stream);
 
+/* Sample-sharded batch statistics WITH gradients (one process per GPU, each holding `rows` rows of the batch): the two
+ * calls above cut at their exchange step.  The reference computes the statistics of the whole batch
+ * (bijectors.py:401-410) and differentiates through them (:414-415); sharded, the per-feature sums have to cross ranks
+ * once in each direction -- torch_nf_amd/distributed.py all-reduces the small buffers between the halves:
+ *   forward   tnf_bn_batch_moments_f32   moments (2 D + 1 doubles) = [sum | sum of squares | rows] of THIS rank's rows
+ *             -- all-reduce(moments, SUM) --
+ *             tnf_bn_batch_normalize_f32 statistics from the reduced moments (count read from moments[2 D]),
+ *                                        z_out = this rank's rows normalised; workspace: D floats
+ *   backward  tnf_bn_batch_backward_sums_f32   sums (2 D doubles) = [sum g | sum g x^] of this rank's rows
+ *             -- all-reduce(sums, SUM) --
+ *             tnf_bn_batch_backward_apply_f32  g_z = (g - sum g / n - x^ (sum g x^ + g_log_det) / n) / alpha with
+ *                                              n = *count (device pointer to the reduced moments[2 D])
+ * rows may be 0 (an empty shard still takes part in the reductions). */
+int tnf_bn_batch_moments_f32(const float* z, double* moments, int64_t rows, int32_t D, void* stream);
+int tnf_bn_batch_normalize_f32(const float* z, const double* moments, float* z_out, float* mean_out, float* alpha_out,
+                               float* log_det, int64_t rows, int32_t D, float eps, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+int tnf_bn_batch_backward_sums_f32(const float* z_norm, const float* g_z_out, double* sums, int64_t rows, int32_t D,
+                                   void* stream);
+int tnf_bn_batch_backward_apply_f32(const float* z_norm, const float* g_z_out, const float* g_log_det,
+                                    const float* alpha, const double* sums, const double* count, float* g_z,
+                                    int64_t rows, int32_t D, void* stream);
+
 /* ---- MAF, the bijector of NormFlow's default arch_type "AR" (bijectors.py:597-806) ----------
  * Twin masked MLPs without biases; params = [W_mu0 | W_alpha0 | ... | W_mu_last | W_alpha_last]
  * (bijectors.py:698-740), W row-major [in][out]; `masks` = the binary matrices Ms of

@@ -710,3 +710,44 @@ def test_flow_reversible_backward_magic_form(tnf, oracle, D, S, L, U, M, Mp, N):
         assert float((gp - pr.grad).abs().max()) <= 1e-4 * sp
         assert float((gz - zr.grad).abs().max()) <= 2e-5 * sz
     assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+
+
+@pytest.mark.parametrize("arch,D,S", [("coupling", 64, 2), ("AR", 6, 1)])
+def test_sharded_batch_statistics_under_autograd_one_rank(tnf, oracle, arch, D, S):
+    """The sample-sharded batch-statistics path under autograd (NormFlow.batch_stats_reduce with gradients: per-bijector
+    composition, BatchNorm layers cut at their exchange steps -- tnf_bn_batch_moments / _normalize / _backward_sums /
+    _backward_apply) with a one-rank reducer: same samples, log-density, cached statistics and gradients as torch
+    autograd over the oracle.  The exchange itself is tests/test_distributed_gloo.py's (two gloo ranks)."""
+    L, U, M, N = 2, 15, 2, 80
+    rng = np.random.RandomState(D)
+    np.random.seed(3)
+    nf = tnf.NormFlow(D, True, arch, S, L, U)
+    calls = []
+
+    def one_rank(t):
+        calls.append(tuple(t.shape))
+        return t
+
+    nf.batch_stats_reduce = one_rank
+    p0 = torch.tensor(rng.normal(0, 0.1, (M, nf.D_params))).float()
+    omega = rng.normal(0, 1, (M, N, D))
+    w = torch.tensor(rng.uniform(0.5, 1.5, (M, N))).float()
+    pr = p0.clone().requires_grad_()
+    if arch == "coupling":
+        z_r, lq_r, _ = oracle.flow_forward(omega, pr, D, S, L, U, None)
+    else:
+        Ms = [Mk[0].numpy() for Mk in nf.bijectors[0].Ms]
+        z_r, lq_r, _ = oracle.ar_flow_forward(omega, pr, D, L, U, Ms, None)
+    ((lq_r * w).mean() + (z_r.double() ** 2).mean()).backward()
+    p = p0.cuda().requires_grad_()
+    z, lq = nf._forward_from(omega, p, freeze_bn=False)
+    ((lq * w.cuda()).mean() + (z.double() ** 2).mean()).backward()
+    n_bn = len(nf._bn_layers())
+    assert len(calls) == 2 * n_bn, calls  # one exchange per BatchNorm layer and direction
+    torch.testing.assert_close(z.cpu(), z_r.detach().float(), rtol=1e-4, atol=1e-4)
+    sp = float(pr.grad.abs().max())
+    torch.testing.assert_close(p.grad.cpu() / sp, pr.grad / sp, rtol=5e-3, atol=2e-4)
+    # frozen statistics do not exchange anything
+    with torch.no_grad():
+        nf._forward_from(omega, p0.cuda(), freeze_bn=True)
+    assert len(calls) == 2 * n_bn

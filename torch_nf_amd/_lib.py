@@ -43,6 +43,10 @@ SIGNATURES = {
     "tnf_bn_apply": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "tnf_bn_batch_workspace_bytes": (_i64, [_i32]),
     "tnf_bn_batch_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
+    "tnf_bn_batch_moments_f32": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "tnf_bn_batch_normalize_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _i64, _vp]),
+    "tnf_bn_batch_backward_sums_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "tnf_bn_batch_backward_apply_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "tnf_coupling_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                              _i32, _i32, _i32, _i64, _i64, _vp]),
     "tnf_affine_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,

@@ -203,6 +203,10 @@ class BatchNorm(Bijector):
         self._last_mean = torch.tensor(np.zeros(D)).float()
         self._last_alpha = torch.tensor(np.ones(D)).float()
         self._version = 0  # bumped whenever the cached statistics change (NormFlow caches the stacked copy)
+        # sample-sharded batches (one process per GPU): a callable that sums a small tensor in place over the ranks
+        # holding the other rows (distributed.moment_reducer(group)); batch-mode forward and its backward then use the
+        # statistics of the WHOLE batch.  None: this process holds the whole batch.
+        self.stats_reduce = None
 
     def get_last_mean(self):
         return self._last_mean
@@ -240,7 +244,7 @@ class BatchNorm(Bijector):
     def forward_and_log_det(self, z, use_last=False):
         if use_last:
             return ops.bn_apply(z, *self._stats_for(z), False)
-        z_norm, log_det, mean, alpha = ops.bn_batch_forward(z, self.eps)
+        z_norm, log_det, mean, alpha = ops.bn_batch_forward(z, self.eps, reduce=self.stats_reduce)
         self._last_mean, self._last_alpha = mean, alpha
         self._version += 1
         return z_norm, log_det

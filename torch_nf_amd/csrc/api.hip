@@ -334,6 +334,40 @@ int tnf_bn_batch_backward_f32(const float* z_norm, const float* g_z_out, const f
     return launch_bn_batch_backward(z_norm, g_z_out, g_log_det, alpha, g_z, rows, D, workspace, as_stream(stream));
 }
 
+int tnf_bn_batch_moments_f32(const float* z, double* moments, int64_t rows, int32_t D, void* stream) {
+    if (rows < 0 || D < 1 || !moments || (rows > 0 && !z))
+        return fail(TNF_EINVAL, "tnf_bn_batch_moments_f32: rows=%lld D=%d or NULL pointer", (long long)rows, D);
+    return launch_bn_moments(z, moments, rows, D, as_stream(stream));
+}
+
+int tnf_bn_batch_normalize_f32(const float* z, const double* moments, float* z_out, float* mean_out, float* alpha_out,
+                               float* log_det, int64_t rows, int32_t D, float eps, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    if (rows < 0 || D < 1) return fail(TNF_EINVAL, "tnf_bn_batch_normalize_f32: rows=%lld D=%d", (long long)rows, D);
+    if (!moments || !mean_out || !alpha_out || !log_det || !workspace || (rows > 0 && (!z || !z_out)))
+        return fail(TNF_EINVAL, "tnf_bn_batch_normalize_f32: NULL pointer");
+    if (workspace_bytes < (int64_t)D * (int64_t)sizeof(float))
+        return fail(TNF_EWORKSPACE, "tnf_bn_batch_normalize_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)D * (long long)sizeof(float));
+    return launch_bn_normalize_from_moments(z, moments, z_out, mean_out, alpha_out, log_det,
+                                            reinterpret_cast<float*>(workspace), rows, D, eps, as_stream(stream));
+}
+
+int tnf_bn_batch_backward_sums_f32(const float* z_norm, const float* g_z_out, double* sums, int64_t rows, int32_t D,
+                                   void* stream) {
+    if (rows < 0 || D < 1 || !sums || (rows > 0 && (!z_norm || !g_z_out)))
+        return fail(TNF_EINVAL, "tnf_bn_batch_backward_sums_f32: rows=%lld D=%d or NULL pointer", (long long)rows, D);
+    return launch_bn_batch_backward_sums(z_norm, g_z_out, sums, rows, D, as_stream(stream));
+}
+
+int tnf_bn_batch_backward_apply_f32(const float* z_norm, const float* g_z_out, const float* g_log_det,
+                                    const float* alpha, const double* sums, const double* count, float* g_z,
+                                    int64_t rows, int32_t D, void* stream) {
+    if (rows < 0 || D < 1 || !alpha || !sums || !count || (rows > 0 && (!z_norm || !g_z_out || !g_z)))
+        return fail(TNF_EINVAL, "tnf_bn_batch_backward_apply_f32: rows=%lld D=%d or NULL pointer", (long long)rows, D);
+    return launch_bn_batch_backward_apply(z_norm, g_z_out, g_log_det, alpha, sums, count, g_z, rows, D, as_stream(stream));
+}
+
 int64_t tnf_maf_num_params(int32_t D, int32_t L, int32_t U) {
     if (D < 1 || L < 1 || U < 1) return fail(TNF_EINVAL, "tnf_maf_num_params: D=%d L=%d U=%d", D, L, U);
     return 2 * (2 * (int64_t)D * U + (int64_t)(L - 1) * U * U);

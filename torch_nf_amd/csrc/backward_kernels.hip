@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(256)
 bn_batch_bwd_apply_kernel(const float* __restrict__ zn, const float* __restrict__ g,
                           const float* __restrict__ g_ld, const float* __restrict__ alpha,
                           const double* __restrict__ sums, float* __restrict__ g_z, int64_t rows, int D,
-                          int64_t total) {
-    const double inv_n = 1.0 / (double)rows;
+                          int64_t total, const double* __restrict__ count) {
+    const double inv_n = 1.0 / (count ? *count : (double)rows);  // count: the GLOBAL row count of a sample-sharded batch
     const double gl = g_ld ? (double)*g_ld : 0.0;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int d = (int)(idx % D);
@@ -424,22 +424,35 @@ bn_batch_bwd_apply_kernel(const float* __restrict__ zn, const float* __restrict_
     }
 }
 
-int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
-                             int64_t rows, int D, void* ws, hipStream_t st) {
-    double* sums = reinterpret_cast<double*>(ws);
+// the two halves of the backward, separately callable: a sample-sharded batch sums `sums` over the ranks in between
+int launch_bn_batch_backward_sums(const float* zn, const float* g, double* sums, int64_t rows, int D, hipStream_t st) {
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * (size_t)D, st) != hipSuccess)
         return fail(TNF_ELAUNCH, "bn_batch_backward: memset failed");
+    if (rows <= 0) return TNF_OK;  // an empty shard contributes zeros
     int64_t blocks = (rows + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     const int64_t rpb = (rows + blocks - 1) / blocks;
     hipLaunchKernelGGL(bn_batch_bwd_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, st, zn, g, sums, rows, D, rpb);
+    return check_launch("bn_batch_backward_sums");
+}
+int launch_bn_batch_backward_apply(const float* zn, const float* g, const float* g_ld, const float* alpha,
+                                   const double* sums, const double* count, float* g_z, int64_t rows, int D,
+                                   hipStream_t st) {
     const int64_t total = rows * D;
+    if (total <= 0) return TNF_OK;
     int64_t nb = (total + 255) / 256;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(bn_batch_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, zn, g, g_ld, alpha, sums, g_z,
-                       rows, D, total);
-    return check_launch("bn_batch_backward");
+                       rows, D, total, count);
+    return check_launch("bn_batch_backward_apply");
+}
+int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
+                             int64_t rows, int D, void* ws, hipStream_t st) {
+    double* sums = reinterpret_cast<double*>(ws);
+    const int rc = launch_bn_batch_backward_sums(zn, g, sums, rows, D, st);
+    if (rc) return rc;
+    return launch_bn_batch_backward_apply(zn, g, g_ld, alpha, sums, nullptr, g_z, rows, D, st);
 }
 
 }  // namespace tnf

@@ -45,6 +45,12 @@
 #ifndef TNF2_ABL
 #define TNF2_ABL 0
 #endif
+// Explicit pipe interleave of the layer body, all measured and none adopted -- DESIGN.md 3.11.2:
+//   1 / 2: __builtin_amdgcn_iglp_opt(0 / 1);  3: one MFMA then five vector instructions, 24 NT times per layer, as
+//   __builtin_amdgcn_sched_group_barrier groups;  4: one MFMA, two transcendentals, three other vector instructions.
+#ifndef TNF2_SCHED
+#define TNF2_SCHED 0
+#endif
 
 namespace tnf {
 
@@ -394,6 +400,13 @@ __device__ __forceinline__ void coupling_tile2(const float* img, int lane, const
     }
     typedef Img2<H, L> I;
     constexpr int HT = I::HT;
+#if TNF2_SCHED == 3 || TNF2_SCHED == 4
+    __builtin_amdgcn_sched_barrier(0);  // one scheduling region per layer (without it the group solver ran > 30 min)
+#elif TNF2_SCHED == 1
+    __builtin_amdgcn_iglp_opt(0);
+#elif TNF2_SCHED == 2
+    __builtin_amdgcn_iglp_opt(1);
+#endif
     const u4* g0 = reinterpret_cast<const u4*>(img) + lane;
     const u4* gd = reinterpret_cast<const u4*>(img + I::OFF_D) + lane;
     const float* bl = img + I::OFF_B + (lane >> 4) * 4;
@@ -520,6 +533,21 @@ __device__ __forceinline__ void coupling_tile2(const float* img, int lane, const
                     y[t][mo][j] = __builtin_fmaf(y[t][mo][j], ay[j], -tt[t][j]) * __builtin_amdgcn_exp2f(-s2);
             }
     }
+#if TNF2_SCHED == 3 || TNF2_SCHED == 4
+    // the layer's MFMAs (3 per contraction: 2 x 3 first-layer + (2 (L - 1) + 2 HT) x 3 K = 16 contractions per tile), each
+    // followed by its share of the vector work
+    constexpr int NMFMA = NT * 3 * (2 + 2 * (L - 1) + 2 * HT);
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+#if TNF2_SCHED == 3
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // VALU
+#else
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);  // transcendental
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+#endif
+    }
+#endif
 }
 
 }  // namespace tnf

@@ -429,6 +429,22 @@ int launch_bn_finalize(const double* moments, float* mean_out, float* alpha_out,
     return check_launch("bn_finalize");
 }
 
+// second half of a sample-sharded batch-statistics forward: statistics from the (all-reduced) moments -- the row count is
+// read from moments[2 D] -- then this rank's rows normalised with them.  rstd: D floats of scratch.
+int launch_bn_normalize_from_moments(const float* z, const double* moments, float* z_out, float* mean_out,
+                                     float* alpha_out, float* log_det, float* rstd, int64_t rows, int D, float eps,
+                                     hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, moments, mean_out, alpha_out, rstd, log_det,
+                       (int64_t)-1, D, eps);
+    const int64_t total = rows * D;
+    if (total > 0) {
+        int64_t nb = (total + 255) / 256;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(bn_normalize_kernel, dim3((unsigned)nb), dim3(256), 0, st, z, mean_out, rstd, z_out, D, total);
+    }
+    return check_launch("bn_normalize_from_moments");
+}
+
 int launch_bn_batch_forward(const float* z, float* z_out, float* mean_out, float* alpha_out,
                             float* log_det, int64_t rows, int D, float eps, void* ws, hipStream_t st) {
     double* sums = reinterpret_cast<double*>(ws);

@@ -259,6 +259,13 @@ int launch_affine_backward(int dtype, const void* z, const void* params, const v
 int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, void* g_z, int64_t rows,
                              int D, int inverse, hipStream_t st);
 
+int launch_bn_normalize_from_moments(const float* z, const double* moments, float* z_out, float* mean_out,
+                                     float* alpha_out, float* log_det, float* rstd, int64_t rows, int D, float eps,
+                                     hipStream_t st);
+int launch_bn_batch_backward_sums(const float* zn, const float* g, double* sums, int64_t rows, int D, hipStream_t st);
+int launch_bn_batch_backward_apply(const float* zn, const float* g, const float* g_ld, const float* alpha,
+                                   const double* sums, const double* count, float* g_z, int64_t rows, int D,
+                                   hipStream_t st);
 int launch_bn_batch_backward(const float* zn, const float* g, const float* g_ld, const float* alpha, float* g_z,
                              int64_t rows, int D, void* ws, hipStream_t st);
 bool cond_flow_supported(int D, int S, int L, int U, int H);

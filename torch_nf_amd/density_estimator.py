@@ -277,14 +277,12 @@ class NormFlow(DensityEstimator):
 
         sup = self._fused_support()
         support_done = False
-        if (not freeze_bn and self.batch_stats_reduce is not None
-                and not (self._fused_ok(z, p_dev) and self._batch_chain_ok(z, p_dev))):
-            # sharded statistics exist only in the stepwise no-autograd chain: anything else would silently
-            # normalise with this rank's local moments
-            raise NotImplementedError(
-                "NormFlow.batch_stats_reduce is set (sample-sharded batch statistics), but this call does not take the "
-                "one-call batch-statistics chain (needs arch_type='coupling', float32, no autograd, D in {32, 64}, "
-                "num_units <= 16, num_layers <= 3, one parameter row per z row).")
+        # sample-sharded batch statistics (self.batch_stats_reduce): the stepwise no-autograd chain exchanges the moments
+        # between its launches; every other case -- autograd, other shapes, arch_type "AR" -- runs the per-bijector
+        # composition with BatchNorm layers that exchange their moments forward and their gradient sums backward
+        # (ops._BnBatchShardedFn).  The one-node training chain computes local moments inside one C call: not offered.
+        for b in self._bn_layers():
+            b.stats_reduce = None if freeze_bn else self.batch_stats_reduce
         if freeze_bn and self._ar_fused_ok(z, p_dev) and sup is not False:
             z, sld = ops.ar_flow_forward_raw(z, p_dev, *self._ar_args(), interval_consts=sup)
             log_q = log_q - sld
@@ -316,7 +314,7 @@ class NormFlow(DensityEstimator):
             for i, b in enumerate(bns):
                 b.set_last_stats(means[i], alphas[i])
             log_q = log_q - sld
-        elif (not freeze_bn and self.arch_type == "coupling" and z.dtype == torch.float32
+        elif (not freeze_bn and self.arch_type == "coupling" and z.dtype == torch.float32 and self.batch_stats_reduce is None
               and p_dev.dtype == torch.float32 and self._batch_chain_ok(z, p_dev) and z.size(0) * z.size(1) >= 32):
             # fresh batch statistics under autograd: one node for the whole stack (gradients through the batch
             # moments included)

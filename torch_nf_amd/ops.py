@@ -286,11 +286,122 @@ class _BnBatchFn(torch.autograd.Function):
         return gz, None
 
 
-def bn_batch_forward(z, eps):
-    """Batch-statistics BatchNorm forward (float32).  Returns (z_norm, log_det, mean, alpha)."""
+def bn_batch_forward(z, eps, reduce=None):
+    """Batch-statistics BatchNorm forward (float32).  Returns (z_norm, log_det, mean, alpha).
+    reduce: the exchange step of a SAMPLE-SHARDED batch (distributed.moment_reducer(group): sums a small tensor in
+    place over the ranks that hold the other rows) -- statistics and their gradients are then those of the whole batch."""
+    if reduce is not None:
+        return bn_batch_forward_sharded(z, eps, reduce)
     if torch.is_grad_enabled() and z.requires_grad:
         return _BnBatchFn.apply(z, eps)
     return _bn_batch_forward_raw(z, eps)
+
+
+class HipBnShardKernels(object):
+    """The four halves of the sample-sharded batch-statistics BatchNorm on the HIP device (tnf_bn_batch_moments_f32,
+    _normalize_f32, _backward_sums_f32, _backward_apply_f32).  bn_batch_forward_sharded takes the kernels as an object so
+    that the CPU tests can drive the same exchange logic with stand-ins (tests/test_distributed_gloo.py)."""
+
+    @staticmethod
+    def moments(z):
+        D = z.shape[-1]
+        mom = torch.empty(2 * D + 1, dtype=torch.float64, device=z.device)
+        check(lib.tnf_bn_batch_moments_f32(z.data_ptr(), mom.data_ptr(), z.numel() // D, D, _lib.stream_ptr()))
+        return mom
+
+    @staticmethod
+    def normalize(z, moments, eps):
+        D = z.shape[-1]
+        dev = z.device
+        z_out = torch.empty_like(z)
+        mean = torch.empty(D, dtype=torch.float32, device=dev)
+        alpha = torch.empty(D, dtype=torch.float32, device=dev)
+        log_det = torch.empty((), dtype=torch.float32, device=dev)
+        ws = torch.empty(D, dtype=torch.float32, device=dev)
+        check(lib.tnf_bn_batch_normalize_f32(z.data_ptr(), moments.data_ptr(), z_out.data_ptr(), mean.data_ptr(),
+                                             alpha.data_ptr(), log_det.data_ptr(), z.numel() // D, D, float(eps),
+                                             ws.data_ptr(), 4 * D, _lib.stream_ptr()))
+        return z_out, log_det, mean, alpha
+
+    @staticmethod
+    def backward_sums(z_norm, g):
+        D = z_norm.shape[-1]
+        sums = torch.empty(2 * D, dtype=torch.float64, device=z_norm.device)
+        check(lib.tnf_bn_batch_backward_sums_f32(z_norm.data_ptr(), g.data_ptr(), sums.data_ptr(), z_norm.numel() // D, D,
+                                                 _lib.stream_ptr()))
+        return sums
+
+    @staticmethod
+    def backward_apply(z_norm, g, g_ld, alpha, sums, count):
+        D = z_norm.shape[-1]
+        out = torch.empty_like(z_norm)
+        check(lib.tnf_bn_batch_backward_apply_f32(z_norm.data_ptr(), g.data_ptr(), None if g_ld is None else g_ld.data_ptr(),
+                                                  alpha.data_ptr(), sums.data_ptr(), count.data_ptr(), out.data_ptr(),
+                                                  z_norm.numel() // D, D, _lib.stream_ptr()))
+        return out
+
+
+class _BnBatchShardedFn(torch.autograd.Function):
+    """_BnBatchFn for a batch whose rows are spread over ranks ("an all-reduce of [sum z, sum z^2] per BN
+    layer ... required for parity with the single-device answer", here WITH gradients -- the reference differentiates
+    through the batch moments, bijectors.py:401-415):
+      forward   local moments -> reduce -> statistics of the whole batch -> this rank's rows normalised
+      backward  local [sum g | sum g x^] -> reduce -> g_z of this rank's rows with the global sums and row count;
+                gradients arriving at the RETURNED statistics (a later use of the cached mean / alpha in the same graph)
+                are summed over the ranks too, since every rank holds a replica of them.
+    Every rank must take part in every reduction, also with an empty shard: the collectives are matched by call order."""
+
+    @staticmethod
+    def forward(ctx, z, eps, reduce, kernels):
+        mom = reduce(kernels.moments(z))
+        z_norm, log_det, mean, alpha = kernels.normalize(z, mom, eps)
+        ctx.save_for_backward(z_norm, alpha, mom)
+        ctx.reduce, ctx.kernels = reduce, kernels
+        return z_norm, log_det, mean, alpha
+
+    @staticmethod
+    def backward(ctx, g_zn, g_ld, g_mean, g_alpha):
+        z_norm, alpha, mom = ctx.saved_tensors
+        reduce, kernels = ctx.reduce, ctx.kernels
+        D = z_norm.shape[-1]
+        g = torch.zeros_like(z_norm) if g_zn is None else g_zn.contiguous().to(z_norm.dtype)
+        sums = kernels.backward_sums(z_norm, g)
+        if g_ld is not None:  # log_det is replicated like the statistics: its gradient rides in the same reduction
+            sums[D:] += g_ld.to(sums.device).double()  # (it meets the sum of g x^ in the formula, tnf.h)
+        sums = reduce(sums)
+        gz = kernels.backward_apply(z_norm, g, None, alpha, sums, mom[2 * D:])
+        # replicas of mean / alpha: their gradient is the sum over the ranks' later uses.  (Structural: present on every
+        # rank or on none -- the ranks run the same graph.)
+        if g_mean is not None or g_alpha is not None:
+            gs = torch.zeros(2 * D, dtype=torch.float64, device=z_norm.device)
+            if g_mean is not None:
+                gs[:D] = g_mean.to(gs.device).double()
+            if g_alpha is not None:
+                gs[D:] = g_alpha.to(gs.device).double()
+            gs = reduce(gs) / mom[2 * D]
+            gz = gz + (gs[:D] + z_norm * gs[D:]).to(gz.dtype)
+        return gz, None, None, None
+
+
+def bn_batch_forward_sharded(z, eps, reduce, kernels=None):
+    """The sample-sharded batch-statistics forward (see _BnBatchShardedFn).  z: this rank's rows (M, N_local, D) float32."""
+    _check3(z)
+    if z.dtype != torch.float32:
+        raise TypeError("BatchNorm batch statistics are implemented for float32 (got %s)" % z.dtype)
+    home = z.device
+    if kernels is None:
+        kernels = HipBnShardKernels
+        dev = _lib.require_device()
+        zc = z if z.device == dev and z.is_contiguous() else z.to(dev).contiguous()
+    else:
+        zc = z.contiguous()
+    if torch.is_grad_enabled() and zc.requires_grad:
+        out = _BnBatchShardedFn.apply(zc, eps, reduce, kernels)
+    else:
+        out = kernels.normalize(zc, reduce(kernels.moments(zc)), eps)
+    if home != zc.device:
+        out = tuple(t.to(home) for t in out)
+    return out
 
 
 def _bn_batch_forward_raw(z, eps):
