@@ -29,6 +29,7 @@ One JSON line is printed by rank 0.  Besides the contract's keys it carries
                    `threads16` = the same at 16 threads);
   layer_chain   -- the same call with one fused kernel per coupling layer (k = 8, the
                    HBM-bound design of north_star), measured after the timed region, with its own roofline;
+  sampling_layer_chain -- (1 GPU) the sampling direction, frozen statistics, one fused kernel per coupling layer;
   parity        -- max relative error of the GPU log_prob vs the oracle on 2^16 samples (ENFORCED: exit code 1
                    when it exceeds the tolerance);
   rccl_ranks    -- sum over ranks of 1 through an RCCL all-reduce (proves N ranks took part);
@@ -517,6 +518,30 @@ def main():
         del nf32, z32
         cfg["configs[2]"] = bench_rows.config2_row(tnf, dev)
         out["configs"] = cfg
+        # the SAMPLING direction with frozen statistics (density_estimator.py:374-388) as the k = 2S chain: one
+        # flow_range2_kernel<.., FWD> launch per coupling layer (round 3; the fp32-MFMA chain it replaces ran at 0.55-0.57)
+        bn_m, bn_a = nf._bn_stats(dev)
+        omega = torch.randn(1, N_PER_GPU, D, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+        with torch.no_grad():
+            settle(lambda: tnf.ops.flow_forward_raw(omega, nf.params, bn_m, bn_a, D, S, L, U, L_.FUSE_LAYER), args.settle_ms)
+            prs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a_, b_ in prs:
+                a_.record()
+                tnf.ops.flow_forward_raw(omega, nf.params, bn_m, bn_a, D, S, L, U, L_.FUSE_LAYER)
+                b_.record()
+            torch.cuda.synchronize()
+        ms_s = float(np.mean([a_.elapsed_time(b_) for a_, b_ in prs]))
+        out["sampling_layer_chain"] = {
+            "what": "NormFlow.forward with frozen statistics (sampling direction), one fused kernel per coupling layer",
+            "value": round(N_PER_GPU / (ms_s * 1e-3) / 1e6, 1), "unit": "M samples/s", "ms_per_step": round(ms_s, 4),
+            "launches": 2 * S,
+            "roofline": {"bound": "hbm", "kernel": "flow_range2_kernel<32,2,2,8,*,*,0,true> (one coupling layer per launch)",
+                         "achieved": round(N_PER_GPU * bytes_per_sample_chain(D, 2 * S) / (ms_s * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(N_PER_GPU * bytes_per_sample_chain(D, 2 * S) / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None,
+                         "algorithmic_bytes_per_sample_all_launches": bytes_per_sample_chain(D, 2 * S)}}
+        del omega
         out["widened"] = bench_rows.widened_rows(tnf)
 
     parity_ok = True

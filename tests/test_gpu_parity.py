@@ -712,10 +712,14 @@ def test_batch_stats_forward_sharded_steps(tnf, D, S, L, M, N, cut):
     assert len(calls) == 2 * S and calls[0] == (2 * D + 1,)
     torch.testing.assert_close(z1, z_ref, rtol=0, atol=0)
     nf.batch_stats_reduce = None
-    # ... and a path that cannot honour the reducer says so instead of using local statistics
-    nf.batch_stats_reduce = lambda mo: mo
-    with pytest.raises(NotImplementedError):
-        nf._forward_from(omega, params.clone().requires_grad_(), freeze_bn=False)
+    # ... and under autograd (round 3) the per-bijector composition honours it too: BatchNorm layers cut at their
+    # exchange steps, one exchange per layer forward (and one backward: tests/test_gpu_grad.py)
+    calls.clear()
+    nf.batch_stats_reduce = lambda mo: calls.append(mo.shape) or mo
+    z2, _ = nf._forward_from(omega, params.clone().requires_grad_(), freeze_bn=False)
+    assert len(calls) == 2 * S and calls[0] == (2 * D + 1,)
+    torch.testing.assert_close(z2.detach(), z_ref, rtol=1e-4, atol=1e-4)
+    nf.batch_stats_reduce = None
 
 
 def _rel_err(got, want):

@@ -1266,6 +1266,11 @@ static int flow_forward_impl(const float* omega, const float* params, const floa
     if (f16)
         return launch_flow_fused_f16(omega, nullptr, nullptr, nullptr, z_out, sum_log_det, nullptr, M_z, M_p, N, D, S, L,
                                      U, 0, g_flow_variant, st, params, pstride, bn_mean, bn_alpha, interval_consts);
+    if (!use_fused && narrow && g_layer_variant >= 10 && flow_range2_supported(D, L, U, 1))
+        // default per-layer chain of the sampling direction: the whole-flow kernel's tile code, ONE coupling layer per
+        // launch, staged 1-KB loads, half-row stores, prepared prologues (flow_range2_kernel<.., FWD>, flow_fused2.hip)
+        return launch_flow_chain2_fwd(omega, z_out, sum_log_det, M_z, M_p, N, D, S, L, U, params, pstride, bn_mean, bn_alpha,
+                                      nullptr, st, images);
     rc = launch_flow_prep(params, bn_mean, bn_alpha, fold, ldc, narrow ? images : nullptr, M_p, D, S, L, U, pstride, 0, st);
     if (rc) return rc;
     if (!narrow) {

@@ -470,11 +470,35 @@ __device__ __forceinline__ void fold_inverse(const Flow2Args& a, const float* pr
     B = mu - shift * A;
 }
 
+// the same map in the sampling direction (BatchNorm, then the Affine behind odd layers): v -> A v + B, the arithmetic
+// of flow_fused2_kernel<.., FWD>'s prologue
+__device__ __forceinline__ void fold_forward(const Flow2Args& a, const float* prow, int D, int c, int d, float& A, float& B) {
+    const float alpha = a.bn_alpha[c * D + d], mu = a.bn_mean[c * D + d];
+    float ea = 1.f, shift = 0.f;
+    if (c & 1) {
+        const float* ap = prow + (c >> 1) * a.stage_stride + a.affine_off;
+        ea = expf(ap[d]);
+        shift = ap[D + d];
+    }
+    A = ea / alpha;
+    B = shift - mu * A;
+}
+
 // HI_FIRST / HI_LAST: layer c_hi / c_lo conditions on the upper half (c odd).  Compile-time, so that the two register
 // halves are never selected by a run-time index (that would put them in scratch memory).
-template <int H, int L, int NT, int NWAVES, bool HI_FIRST, bool HI_LAST, int PREC>
+//
+// FWD = true: ONE coupling layer of the SAMPLING direction per launch (c_hi == c_lo == c, the k = 2S design for
+// NormFlow.forward with frozen statistics, density_estimator.py:374-388): the walk goes c = 0 .. 2S-1 and the BatchNorm /
+// Affine behind a layer (F_c) is applied by nobody -- a half sits in the buffer as the layer that last transformed it
+// emitted it, owing every fold since.  At launch c the conditioner half (emitted by layer c-1) owes F_{c-1}, absorbed by
+// the layer-0 weights; the half this launch transforms (emitted by layer c-2) owes F_{c-2} then F_{c-1}, composed into its
+// Ay, By -- exactly one step of the whole-flow kernel's forward walk (build_image2<.., FWD>: foldc = F_{c-1}, foldprev =
+// F_{c-2}), with the register scales reset at the launch boundary.  Middle launches store only the half they transformed;
+// the last one turns both halves into true values (one fma per feature).
+template <int H, int L, int NT, int NWAVES, bool HI_FIRST, bool HI_LAST, int PREC, bool FWD = false>
 __global__ void __launch_bounds__(NWAVES * 64)
 flow_range2_kernel(Range2Args ra) {
+    static_assert(!FWD || (HI_FIRST == HI_LAST && PREC == 0), "the sampling direction runs one layer per launch, split-f16");
     constexpr int D = 2 * H;
     constexpr int HT = H / 16;
     typedef Img2<H, L> I;
@@ -483,12 +507,16 @@ flow_range2_kernel(Range2Args ra) {
     const int nl = 2 * a.S;
     int c_hi_ = ra.c_hi, c_lo_ = ra.c_lo;
     if (ra.prep_out) {  // preparation launch: workgroup x stands in for launch x of the chain
-        c_hi_ = nl - 1 - (int)blockIdx.x * ra.per_launch;
-        c_lo_ = c_hi_ - ra.per_launch + 1 > 0 ? c_hi_ - ra.per_launch + 1 : 0;
+        if constexpr (FWD) {
+            c_hi_ = c_lo_ = (int)blockIdx.x;
+        } else {
+            c_hi_ = nl - 1 - (int)blockIdx.x * ra.per_launch;
+            c_lo_ = c_hi_ - ra.per_launch + 1 > 0 ? c_hi_ - ra.per_launch + 1 : 0;
+        }
     }
     const int c_hi = c_hi_, c_lo = c_lo_, nr = c_hi - c_lo + 1;
     const int c_top = c_hi < nl - 1 ? c_hi + 1 : c_hi;  // folds are needed for c_lo .. c_top
-    const bool final_ = c_lo == 0;
+    const bool final_ = FWD ? c_hi == nl - 1 : c_lo == 0;
     float* stage = lds;                                // [NWAVES][NT * 16 rows][D]: wave-private staging of the rows in flight
     float* img = lds + NWAVES * NT * 16 * D;           // [nr] image of layer c at index c - c_lo
     float* fold = img + nr * I::FLOATS;                // [nr + 1][A (D) | B (D)], layer c at index c - c_lo
@@ -505,8 +533,8 @@ flow_range2_kernel(Range2Args ra) {
     if (m >= (a.Mz > a.Mp ? a.Mz : a.Mp)) return;
     const int64_t mz = a.Mz == 1 ? 0 : m, mp = a.Mp == 1 ? 0 : m;
     const float* prow = a.params + mp * a.pstride;
-    const bool has_iv = a.iv != nullptr && c_hi == nl - 1;
-    const int launch_ix = (nl - 1 - c_hi) / (ra.per_launch > 0 ? ra.per_launch : 1);
+    const bool has_iv = !FWD && a.iv != nullptr && c_hi == nl - 1;
+    const int launch_ix = FWD ? c_lo : (nl - 1 - c_hi) / (ra.per_launch > 0 ? ra.per_launch : 1);
     const int nlaunch = ra.per_launch > 0 ? (nl + ra.per_launch - 1) / ra.per_launch : 1;
     const int region = range2_region_floats<H, L>(nr);  // img .. ivc, contiguous
 
@@ -514,6 +542,50 @@ flow_range2_kernel(Range2Args ra) {
         const f4* src = reinterpret_cast<const f4*>(ra.prep + ((int64_t)mp * nlaunch + launch_ix) * ra.prep_slot);
         f4* dst = reinterpret_cast<f4*>(img);
         for (int i = threadIdx.x; i < region / 4; i += NWAVES * 64) dst[i] = src[i];
+        __syncthreads();
+    } else if constexpr (FWD) {
+        const int c = c_lo;
+        const float* pl = prow + (c >> 1) * a.stage_stride + (c & 1) * a.low_off;
+        // fold[0] = the map in front of layer c (F_{c-1}; identity for c = 0), fold[1] = the one before (F_{c-2})
+        for (int i = threadIdx.x; i < 2 * D; i += NWAVES * 64) {
+            const int idx = i / D, d = i - idx * D, src = c - 1 - idx;
+            float A = 1.f, B = 0.f;
+            if (src >= 0) fold_forward(a, prow, D, src, d, A, B);
+            fold[idx * 2 * D + d] = A;
+            fold[idx * 2 * D + D + d] = B;
+        }
+        float acc = 0.f;
+        if (final_)
+            for (int i = threadIdx.x; i < nl * D; i += NWAVES * 64) {
+                float A, B, ld;
+                fold_inverse(a, prow, D, i / D, i % D, A, B, ld);
+                acc += ld;
+            }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) red[wave] = acc;
+        if (threadIdx.x == 0) *qhead = NWAVES;
+        __syncthreads();
+        if (wave == 0) {
+            const int kc = layer_kappa<H>(pl, a.U, lane, fold, c);
+            if (lane == 0) kap[0] = kc;
+        }
+        __syncthreads();
+        if (wave == 0)
+            build_image2<H, L, 0, true>(img, pl, a.U, lane, fold, c > 0 ? fold + 2 * D : nullptr, c, pow2i(kap[0]), 1.f, 1.f);
+        __syncthreads();
+        // the last launch owes true values: the half it transformed F_{nl-1}, its conditioner half (registers scaled by
+        // 2^kappa) F_{nl-2} then F_{nl-1}.  Kept where fold[1] was: [A (D) | B (D)] over both halves.
+        if (final_) {
+            const float sc = pow2i(kap[0]);
+            for (int f = threadIdx.x; f < D; f += NWAVES * 64) {
+                const bool cond = (f >= H) == ((c & 1) != 0);
+                float Al, Bl;
+                fold_forward(a, prow, D, c, f, Al, Bl);
+                const float Ap = fold[f], Bp = fold[D + f];
+                fold[2 * D + f] = cond ? Al * Ap * sc : Al;
+                fold[3 * D + f] = cond ? __builtin_fmaf(Al, Bp, Bl) : Bl;
+            }
+        }
         __syncthreads();
     } else {
     {   // prologue A: folds of the range (+ the one owed from the launch before); the constant log-det on the last launch
@@ -692,6 +764,11 @@ flow_range2_kernel(Range2Args ra) {
                 }
     };
     auto layers = [&](auto slow, f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT], float (&ssum)[NT]) {
+        if constexpr (FWD) {
+            if constexpr (HI_FIRST) coupling_tile2<H, L, NT, decltype(slow)::value, 0, true>(img, lane, dhi, dlo, ssum);
+            else coupling_tile2<H, L, NT, decltype(slow)::value, 0, true>(img, lane, dlo, dhi, ssum);
+            return;
+        }
         for (int c = c_hi; c >= c_lo; --c) {
             const float* im = img + (c - c_lo) * I::FLOATS;
             if (c & 1) coupling_tile2<H, L, NT, decltype(slow)::value, PREC>(im, lane, dhi, dlo, ssum);
@@ -740,9 +817,32 @@ flow_range2_kernel(Range2Args ra) {
             layers(std::true_type{}, lo, hi, ssum);
             if (a.slow_count && lane == 0) atomicAdd(a.slow_count, 1u);
         }
+        if constexpr (FWD) {
+            // last launch: both halves become true values; before: the conditioner half leaves as it came (it is stored
+            // only by the first launch, which works out of place)
+            const float* ff = fold + 2 * D;
+#pragma unroll
+            for (int mm = 0; mm < HT; ++mm) {
+                const f4 la = *reinterpret_cast<const f4*>(ff + 16 * mm + 4 * q), lb = *reinterpret_cast<const f4*>(ff + D + 16 * mm + 4 * q);
+                const f4 ha = *reinterpret_cast<const f4*>(ff + H + 16 * mm + 4 * q), hb = *reinterpret_cast<const f4*>(ff + D + H + 16 * mm + 4 * q);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (final_) {
+                            lo[t][mm][j] = __builtin_fmaf(lo[t][mm][j], la[j], lb[j]);
+                            hi[t][mm][j] = __builtin_fmaf(hi[t][mm][j], ha[j], hb[j]);
+                        } else if constexpr (HI_LAST) {
+                            hi[t][mm][j] *= unsc;
+                        } else {
+                            lo[t][mm][j] *= unsc;
+                        }
+                    }
+            }
+        }
         // conditioner half of the last layer: true values on the final launch, its pre-fold values otherwise
 #pragma unroll
-        for (int mm = 0; mm < HT; ++mm) {
+        for (int mm = 0; mm < HT && !FWD; ++mm) {
             const f4 fa = *reinterpret_cast<const f4*>(fin + 16 * mm + 4 * q);
             const f4 fb = *reinterpret_cast<const f4*>(fin + H + 16 * mm + 4 * q);
 #pragma unroll
@@ -898,13 +998,18 @@ int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log
 }
 
 
-template <int H, int L, int PREC>
+template <int H, int L, int PREC, bool FWD = false>
 static int launch_range_t(const Range2Args& ra, int64_t M, hipStream_t st) {
     constexpr int NT = TNF2_RANGE_NT, NW = TNF2_RANGE_NW;
     const size_t smem = (size_t)range2_lds_floats<H, L>(ra.c_hi - ra.c_lo + 1) * sizeof(float);
     const bool hf = (ra.c_hi & 1) != 0, hl = (ra.c_lo & 1) != 0;
-    auto kern = hf ? (hl ? flow_range2_kernel<H, L, NT, NW, true, true, PREC> : flow_range2_kernel<H, L, NT, NW, true, false, PREC>)
-                   : (hl ? flow_range2_kernel<H, L, NT, NW, false, true, PREC> : flow_range2_kernel<H, L, NT, NW, false, false, PREC>);
+    void (*kern)(Range2Args);
+    if constexpr (FWD) {
+        kern = hf ? flow_range2_kernel<H, L, NT, NW, true, true, 0, true> : flow_range2_kernel<H, L, NT, NW, false, false, 0, true>;
+    } else {
+        kern = hf ? (hl ? flow_range2_kernel<H, L, NT, NW, true, true, PREC> : flow_range2_kernel<H, L, NT, NW, true, false, PREC>)
+                  : (hl ? flow_range2_kernel<H, L, NT, NW, false, true, PREC> : flow_range2_kernel<H, L, NT, NW, false, false, PREC>);
+    }
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_range2: cannot reserve %zu B of LDS", smem);
     const int64_t ngroups = (ra.f.N + 16 * NT - 1) / (16 * NT);
@@ -916,11 +1021,11 @@ static int launch_range_t(const Range2Args& ra, int64_t M, hipStream_t st) {
 }
 
 // the preparation launch of a chain (Range2Args::prep_out): one workgroup per (launch of the chain, context)
-template <int H, int L, int PREC>
+template <int H, int L, int PREC, bool FWD = false>
 static int launch_range_prep_t(const Range2Args& ra, int64_t Mp, int nlaunch, hipStream_t st) {
     constexpr int NT = TNF2_RANGE_NT, NW = TNF2_RANGE_NW;
     const size_t smem = (size_t)range2_lds_floats<H, L>(ra.per_launch) * sizeof(float);
-    auto kern = flow_range2_kernel<H, L, NT, NW, false, false, PREC>;
+    auto kern = flow_range2_kernel<H, L, NT, NW, false, false, PREC, FWD>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return fail(TNF_ELAUNCH, "flow_range2 (preparation): cannot reserve %zu B of LDS", smem);
     hipLaunchKernelGGL(kern, grid_xm(nlaunch, Mp), dim3(NW * 64), smem, st, ra);
@@ -1009,6 +1114,62 @@ int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, flo
         if (rc != TNF_OK) return rc;
     }
     return check_launch("flow_chain2");
+}
+
+// NormFlow.forward with frozen statistics (the sampling direction) as a chain of 2S launches, one coupling layer each:
+// flow_range2_kernel<.., FWD = true>.  omega -> z (out of place on the first launch, in place afterwards; middle launches
+// store only the half they transformed), sum_log_det = running log-det buffer and result.
+int launch_flow_chain2_fwd(const float* omega, float* z, float* sum_log_det, int64_t Mz, int64_t Mp, int64_t N, int D, int S,
+                           int L, int U, const float* params, int64_t pstride, const float* bn_mean, const float* bn_alpha,
+                           unsigned* slow_count, hipStream_t st, float* prep_ws) {
+    const int nl = 2 * S;
+    if (!flow_range2_supported(D, L, U, 1)) return fail(TNF_EUNSUPPORTED, "flow_chain2_fwd: no kernel for D=%d L=%d U=%d", D, L, U);
+    if (N <= 0) return TNF_OK;
+    const int64_t M = Mz > Mp ? Mz : Mp;
+    const FlowLayout fl = flow_layout(D, S, L, U);
+    const int64_t prep_slot = flow_chain2_prep_floats(D, S, L, 1) / nl;
+    if (nl < 2) prep_ws = nullptr;
+    int rc;
+#define TNF_FWD_DISPATCH(CALL)                                                              \
+    if (D == 64) {                                                                          \
+        if (L == 1) rc = CALL(32, 1); else if (L == 2) rc = CALL(32, 2); else rc = CALL(32, 3); \
+    } else {                                                                                \
+        if (L == 1) rc = CALL(16, 1); else if (L == 2) rc = CALL(16, 2); else rc = CALL(16, 3); \
+    }
+    if (prep_ws) {
+        Range2Args ra;
+        ra.f = Flow2Args{omega, nullptr, nullptr, nullptr, Mp, Mp, N, S, U, params, bn_mean, bn_alpha, pstride, fl.stage,
+                         fl.p_up + fl.p_low, fl.p_up, nullptr, nullptr};
+        ra.c_hi = ra.c_lo = 0;
+        ra.ld_in = nullptr;
+        ra.store_cond = 0;
+        ra.prep = nullptr;
+        ra.prep_out = prep_ws;
+        ra.per_launch = 1;
+        ra.prep_slot = prep_slot;
+#define TNF_FWD_PREP(HH, LL) launch_range_prep_t<HH, LL, 0, true>(ra, Mp, nl, st)
+        TNF_FWD_DISPATCH(TNF_FWD_PREP)
+#undef TNF_FWD_PREP
+        if (rc != TNF_OK) return rc;
+    }
+    for (int c = 0; c < nl; ++c) {
+        Range2Args ra;
+        ra.f = Flow2Args{c == 0 ? omega : z, z, sum_log_det, nullptr, c == 0 ? Mz : M, Mp, N, S, U, params, bn_mean, bn_alpha,
+                         pstride, fl.stage, fl.p_up + fl.p_low, fl.p_up, nullptr, slow_count};
+        ra.c_hi = ra.c_lo = c;
+        ra.ld_in = c == 0 ? nullptr : sum_log_det;
+        ra.store_cond = c == 0 ? 1 : 0;  // the first launch works out of place: the conditioner half moves too
+        ra.prep = prep_ws;
+        ra.prep_out = nullptr;
+        ra.per_launch = 1;
+        ra.prep_slot = prep_slot;
+#define TNF_FWD_RANGE(HH, LL) launch_range_t<HH, LL, 0, true>(ra, M, st)
+        TNF_FWD_DISPATCH(TNF_FWD_RANGE)
+#undef TNF_FWD_RANGE
+        if (rc != TNF_OK) return rc;
+    }
+#undef TNF_FWD_DISPATCH
+    return check_launch("flow_chain2_fwd");
 }
 
 }  // namespace tnf

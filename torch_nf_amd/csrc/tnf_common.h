@@ -167,6 +167,9 @@ int launch_flow_chain2(const float* z, float* zbuf, float* ldbuf, float* z0, flo
                        const float* bn_mean, const float* bn_alpha, const float* interval_consts, unsigned* slow_count,
                        int per_launch, hipStream_t st, int prec = 0,  // prec 1: the bf16 experiment (f16_tile2.h)
                        float* prep_ws = nullptr);  // flow_chain2_prep_floats(...) * Mp floats: prologues prepared by one launch
+int launch_flow_chain2_fwd(const float* omega, float* z, float* sum_log_det, int64_t Mz, int64_t Mp, int64_t N, int D, int S,
+                           int L, int U, const float* params, int64_t pstride, const float* bn_mean, const float* bn_alpha,
+                           unsigned* slow_count, hipStream_t st, float* prep_ws);
 int64_t flow_chain2_prep_floats(int D, int S, int L, int per_launch);
 // split-f16 variant of the whole-flow kernel (flow_fused_f16.hip); images in slots of mfma_image_floats(D, 3)
 int launch_flow_images_f16(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,

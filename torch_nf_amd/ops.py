@@ -355,6 +355,7 @@ class _BnBatchShardedFn(torch.autograd.Function):
     def forward(ctx, z, eps, reduce, kernels):
         mom = reduce(kernels.moments(z))
         z_norm, log_det, mean, alpha = kernels.normalize(z, mom, eps)
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None: no exchange for statistics nobody used again
         ctx.save_for_backward(z_norm, alpha, mom)
         ctx.reduce, ctx.kernels = reduce, kernels
         return z_norm, log_det, mean, alpha
