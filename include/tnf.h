@@ -252,6 +252,16 @@ int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, c
                                int32_t num_units, int32_t H, int64_t ldh, int64_t ldw, void* workspace,
                                int64_t workspace_bytes, void* stream);
 
+/* The SAMPLING direction of the same path: ConditionalDensityEstimator.__call__(x, N = 1) with frozen statistics
+ * (conditional_density_estimator.py:93-99 over density_estimator.py:374-388): omega (M, D) base draws, one per
+ * context, pushed forwards through the flow whose parameters are generated from h on the fly; z_out (M, D),
+ * sum_log_det (M) = the forward log-dets (log q(z) = log N(omega; 0, I) - sum_log_det).  Same shapes, alignment and
+ * workspace (tnf_cond_flow_workspace_bytes) as tnf_cond_flow_log_prob_f32. */
+int tnf_cond_flow_forward_f32(const float* omega, const float* h, const float* W, const float* b,
+                              const float* bn_mean, const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M,
+                              int32_t D, int32_t num_stages, int32_t num_layers, int32_t num_units, int32_t H,
+                              int64_t ldh, int64_t ldw, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Training pair of the same path.  tnf_cond_flow_log_prob_fwd_f32 = tnf_cond_flow_log_prob_f32 that also
  * saves, in `acts` (tnf_cond_flow_acts_floats(M, D, S, L) floats), the activations the backward needs.
  * tnf_cond_flow_log_prob_bwd_f32: from g_log_prob (M) to the gradients of param_net's last Linear --

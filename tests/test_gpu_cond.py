@@ -190,3 +190,45 @@ def test_cond_flow_training_tiny_upstream_gradient(tnf):
         grads.append([p.grad.clone() / scale for p in cde.param_net.parameters()])
     for a, b in zip(*grads):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("D,S,L,U,Dx,hidden,M", [
+    (64, 4, 2, 15, 32, [64, 64], 300), (32, 2, 3, 16, 10, [50, 100], 17), (64, 1, 1, 15, 8, [32], 70000),
+])
+def test_cond_flow_sampling_direction(tnf, oracle, D, S, L, U, Dx, hidden, M):
+    """cde(x, N = 1, freeze_bn = True) through the fused conditioner + flow kernel in its SAMPLING direction
+    (tnf_cond_flow_forward_f32; conditional_density_estimator.py:93-99 over density_estimator.py:374-388): samples and
+    log-density against the CPU oracle's flow_forward on the same host draw (np.random.seed) and frozen statistics, against
+    the materialised path of this package, and log_prob(z, x) == log_q on the samples just drawn."""
+    nf, cde = _make(tnf, D, S, L, U, Dx, hidden, seed=M)
+    x = torch.randn(M, Dx, generator=torch.Generator().manual_seed(1))
+    xd = x.cuda()
+    with torch.no_grad():
+        assert cde._fused_sampling_ok(xd)
+        np.random.seed(7)
+        z, lq = cde(xd, N=1, freeze_bn=True)
+        np.random.seed(7)
+        cde.fuse_conditioner = False
+        z_m, lq_m = cde(xd, N=1, freeze_bn=True)
+        cde.fuse_conditioner = True
+        lp = cde.log_prob(z, xd)
+    assert z.shape == (M, 1, D) and lq.shape == (M, 1) and lq.dtype == torch.float64
+    torch.testing.assert_close(z, z_m, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(lq, lq_m, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(lp.double(), lq, rtol=1e-5, atol=2e-4)
+    if M <= 1000:  # the oracle on the same draw
+        np.random.seed(7)
+        omega = np.random.normal(0.0, 1.0, (M, 1, D))
+        net = cde.param_net.cpu().double()
+        params = net(x.double()).float()
+        cde.param_net.float().cuda()
+        stats = [(b.get_last_mean().cpu().float(), b.get_last_alpha().cpu().float()) for b in nf._bn_layers()]
+        z_r, lq_r, _ = oracle.flow_forward(omega, params, D, S, L, U, stats)
+        torch.testing.assert_close(z.cpu(), z_r.float(), rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(lq.cpu(), lq_r.double(), rtol=1e-5, atol=1e-4)
+    # the device-draw variant takes the same kernel; under autograd with a trainable context network it stands back
+    with torch.no_grad():
+        z_s, lq_s = cde.sample(xd, N=1, generator=torch.Generator(device="cuda").manual_seed(3))
+        lp_s = cde.log_prob(z_s, xd)
+    torch.testing.assert_close(lp_s.double(), lq_s, rtol=1e-5, atol=2e-4)
+    assert not cde._fused_sampling_ok(xd)  # grad mode, parameters require grad

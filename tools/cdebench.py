@@ -83,3 +83,21 @@ for M in (1 << 12, 1 << 16, 1 << 18, 1 << 20):
     print("M=%8d  fused: log_prob %8.3f ms (%7.1f M ctx/s)  train step %8.3f ms (%6.2f M ctx/s) | materialised: "
           "log_prob %8.3f ms  train step %8.3f ms" % (M, row[0] * 1e3, M / row[0] / 1e6, row[1] * 1e3, M / row[1] / 1e6,
                                                       row[2] * 1e3, row[3] * 1e3))
+
+print("one sample per context (N = 1), SAMPLING: cde.sample(x, N=1) (device draw, frozen statistics)")
+for M in (1 << 12, 1 << 16, 1 << 18, 1 << 20):
+    x = torch.randn(M, D_x, device="cuda")
+
+    def draw():
+        with torch.no_grad():
+            cde.sample(x, N=1)
+
+    row = []
+    for fused in (True, False):
+        if not fused and M > args.max_materialised:
+            row.append(float("nan"))
+            continue
+        cde.fuse_conditioner = fused
+        row.append(timeit(draw, 5))
+    cde.fuse_conditioner = True
+    print("M=%8d  fused: %8.3f ms (%7.1f M samples/s) | materialised: %8.3f ms" % (M, row[0] * 1e3, M / row[0] / 1e6, row[1] * 1e3))

@@ -57,6 +57,8 @@ SIGNATURES = {
     "tnf_cond_flow_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "tnf_cond_flow_log_prob_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
                                                    _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
+    "tnf_cond_flow_forward_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
+                                                  _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
     "tnf_cond_flow_acts_floats": (_i64, [_i64, _i32, _i32, _i32]),
     "tnf_cond_flow_deltas_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),
     "tnf_cond_flow_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),

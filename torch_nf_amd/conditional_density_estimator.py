@@ -9,6 +9,7 @@ with per-context weights (M_p = M).
 """
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -95,7 +96,15 @@ class ConditionalDensityEstimator(torch.nn.Module):
         return self.param_net(x)
 
     def __call__(self, x, N=100, freeze_bn=False):
-        """conditional_density_estimator.py:93-99: (z (M,N,D), log_q (M,N))."""
+        """conditional_density_estimator.py:93-99: (z (M,N,D), log_q (M,N)).  One sample per context with frozen
+        statistics runs the fused conditioner + flow kernel in its sampling direction (tnf_cond_flow_forward_f32): like
+        `log_prob`'s fused path, the (M, D_params) parameter tensor is never materialised."""
+        if N == 1 and freeze_bn and self._fused_sampling_ok(x):
+            nf = self.density_estimator
+            omega = np.random.normal(0.0, 1.0, (x.size(0), 1, nf.D))  # the reference's host draw (density_estimator.py:366)
+            o64 = torch.as_tensor(omega, dtype=torch.float64).to(_lib.require_device())
+            z, sld = self._fused_sampling(x, o64.float())
+            return self._home(x, z, ops.base_log_density_f64(o64) - sld)
         params = self._params_for(x)
         return self.density_estimator(N=N, params=params, freeze_bn=freeze_bn)
 
@@ -103,8 +112,45 @@ class ConditionalDensityEstimator(torch.nn.Module):
         """Extension (not in the reference): like `__call__`, but the base draw comes from the device RNG
         (`NormFlow.sample`), so posterior sampling is not bound by `np.random.normal` and the PCIe copy
         (2*10^5 draws at D=6: 13 ms through `cde(x0, N)`, 0.3 ms here).  Not reproducible against np.random.seed."""
+        if N == 1 and freeze_bn and self._fused_sampling_ok(x):
+            omega = torch.randn((x.size(0), 1, self.density_estimator.D), device=_lib.require_device(),
+                                dtype=torch.float32, generator=generator)
+            z, sld = self._fused_sampling(x, omega)
+            return self._home(x, z, ops.base_log_density_f64(omega) - sld)
         params = self._params_for(x)
         return self.density_estimator.sample(N, params, freeze_bn=freeze_bn, generator=generator)
+
+    def _home(self, x, z, log_q):
+        home = next(self.param_net.parameters()).device  # where NormFlow would return them: the parameters' device
+        return (z if z.device == home else z.to(home)), (log_q if log_q.device == home else log_q.to(home))
+
+    def _fused_sampling_ok(self, x):
+        """cde(x, N = 1) with frozen statistics on a coupling flow, outside autograd (the samples' gradient with respect
+        to the context network goes through the materialised path)."""
+        nf = self.density_estimator
+        last = self.param_net[-1]
+        if not (self.fuse_conditioner and x.dim() == 2 and x.size(0) >= self.fuse_min_contexts):
+            return False
+        if nf.arch_type != "coupling" or nf.support_layer is not None or nf._stats_in_graph():
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.param_net.parameters())):
+            return False
+        if x.dtype != torch.float32 or last.weight.dtype != torch.float32:
+            return False
+        return ops.cond_flow_supported(nf.D, nf.num_stages, nf.num_layers, nf.num_units, last.in_features)
+
+    def _fused_sampling(self, x, omega):
+        """omega (M, 1, D) float32 on the device -> (z (M, 1, D), sum_log_det (M, 1))."""
+        nf = self.density_estimator
+        last = self.param_net[-1]
+        weight = last.weight
+        xd = x if x.device == weight.device else x.to(weight.device)
+        with torch.no_grad():
+            h = self.param_net[:-1](xd) if len(self.param_net) > 1 else xd
+        mean, alpha = nf._bn_stats(_lib.require_device())
+        z, sld = ops.cond_flow_forward_raw(omega[:, 0, :], h, weight, last.bias, mean, alpha, nf.D, nf.num_stages,
+                                           nf.num_layers, nf.num_units)
+        return z[:, None, :], sld[:, None]
 
     def _fused_conditioner_ok(self, z, x):
         """One sample per context (the SNPE layout z[:, None, :]) on a coupling flow: the last Linear

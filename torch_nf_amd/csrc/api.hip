@@ -565,6 +565,30 @@ int tnf_cond_flow_log_prob_f32(const float* z, const float* h, const float* W, c
                                      H, ldh, ldw, workspace, as_stream(stream));
 }
 
+int tnf_cond_flow_forward_f32(const float* omega, const float* h, const float* W, const float* b,
+                              const float* bn_mean, const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M,
+                              int32_t D, int32_t S, int32_t L, int32_t U, int32_t H, int64_t ldh, int64_t ldw,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M < 0) return fail(TNF_EINVAL, "tnf_cond_flow_forward_f32: M=%lld", (long long)M);
+    if (!cond_flow_supported(D, S, L, U, H))
+        return fail(TNF_EUNSUPPORTED, "tnf_cond_flow_forward_f32: no kernel for D=%d S=%d L=%d U=%d H=%d", D, S, L, U, H);
+    if (ldh < H || ldw < H || (ldh & 3) || (ldw & 3))
+        return fail(TNF_EINVAL, "tnf_cond_flow_forward_f32: ldh=%lld ldw=%lld must be multiples of 4 and >= H=%d",
+                    (long long)ldh, (long long)ldw, H);
+    if (M == 0) return TNF_OK;
+    if (!omega || !h || !W || !b || !bn_mean || !bn_alpha || !z_out || !sum_log_det || !workspace)
+        return fail(TNF_EINVAL, "tnf_cond_flow_forward_f32: NULL pointer");
+    if (((uintptr_t)h & 15) || ((uintptr_t)W & 15) || ((uintptr_t)omega & 15) || ((uintptr_t)z_out & 15) ||
+        ((uintptr_t)workspace & 255))
+        return fail(TNF_EINVAL, "tnf_cond_flow_forward_f32: omega, z_out, h, W must be 16-byte and the workspace 256-byte aligned");
+    const int64_t need = cond_flow_workspace(D, S, L, U, H);
+    if (workspace_bytes < need)
+        return fail(TNF_EWORKSPACE, "tnf_cond_flow_forward_f32: workspace %lld < %lld", (long long)workspace_bytes,
+                    (long long)need);
+    return launch_cond_flow_forward(omega, h, W, b, bn_mean, bn_alpha, z_out, sum_log_det, M, D, S, L, U, H, ldh, ldw,
+                                    workspace, as_stream(stream));
+}
+
 int64_t tnf_cond_flow_acts_floats(int64_t M, int32_t D, int32_t S, int32_t L) {
     if (M < 0 || D < 2 || S < 1 || L < 1) return fail(TNF_EINVAL, "tnf_cond_flow_acts_floats: M=%lld D=%d S=%d L=%d", (long long)M, D, S, L);
     return cond_acts_floats(M, D, S, L);

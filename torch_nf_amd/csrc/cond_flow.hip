@@ -58,7 +58,8 @@ cond_image_kernel(const float* __restrict__ W, const float* __restrict__ b, int6
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < cfg.T; t += (int64_t)gridDim.x * 4) {
         int64_t base;
         int count;
-        if (backward_order) cond_tile_desc_bwd(cfg, t, base, count);
+        if (backward_order == 2) cond_tile_desc_fwd(cfg, t, base, count);  // the sampling program
+        else if (backward_order) cond_tile_desc_bwd(cfg, t, base, count);
         else cond_tile_desc(cfg, t, base, count);
         const bool ok = r < count;
         const float* wr = W + (base + (ok ? r : 0)) * ldw;
@@ -101,9 +102,13 @@ struct CondArgs {
     int S, L, U;
 };
 
-template <int DT, int KS, int BT, int NW, bool SAVE>
+// FWD = true: the SAMPLING direction (cde(x, N = 1) with frozen statistics, conditional_density_estimator.py:93-99 over
+// density_estimator.py:374-388): a.z holds the base draws, the tile stream is the sampling program (cond_tile_desc_fwd),
+// every bijector runs forwards; a.z0 receives the samples, a.sum_log_det the forward log-dets, a.log_prob is unused.
+template <int DT, int KS, int BT, int NW, bool SAVE, bool FWD = false>
 __global__ void __launch_bounds__(64 * NW)
 cond_flow_kernel(CondArgs a) {
+    static_assert(!(SAVE && FWD), "the training forward is the inverse pass");
     constexpr int D = 16 * DT, Hd = D / 2, HT = DT / 2;
     constexpr int ZS = D + 4, HS = 20, CT = 16 * BT;
     typedef TileStream<KS * 128 + 4, kCondG<KS>, NW, kCondNS<KS, BT, NW>> Stream;
@@ -309,7 +314,8 @@ cond_flow_kernel(CondArgs a) {
                 f4 zv = *zp;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    zv[j] = (zv[j] - t4[j]) * fast_exp(-s4[j]);
+                    if constexpr (FWD) zv[j] = __builtin_fmaf(zv[j], fast_exp(s4[j]), t4[j]);  // bijectors.py:172
+                    else zv[j] = (zv[j] - t4[j]) * fast_exp(-s4[j]);
                     ld[bt] += s4[j];
                 }
                 *zp = zv;
@@ -322,7 +328,57 @@ cond_flow_kernel(CondArgs a) {
         }
     };
 
-    for (int si = 0; si < a.S; ++si) {
+    // BatchNorm with cached statistics, forwards (bijectors.py:397-399): (z - mean) / alpha, log_det = -sum log alpha
+    auto bn_forward = [&](int layer) {
+        const float* bnA = a.bn_alpha + (int64_t)layer * D;
+        const float* bnM = a.bn_mean + (int64_t)layer * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const f4 al = *reinterpret_cast<const f4*>(bnA + 16 * t + 4 * q);
+            const f4 mu = *reinterpret_cast<const f4*>(bnM + 16 * t + 4 * q);
+            float lal = 0.f;
+            f4 ia;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lal += fast_log(al[j]);
+                ia[j] = 1.f / al[j];
+            }
+#pragma unroll
+            for (int bt = 0; bt < BT; ++bt) {
+                f4* zp = reinterpret_cast<f4*>(zb + (bt * 16 + c) * ZS + 16 * t + 4 * q);
+                *zp = (*zp - mu) * ia;
+                ld[bt] -= lal;
+            }
+        }
+    };
+    if constexpr (FWD) {
+        for (int st = 0; st < a.S; ++st) {
+            coupling(0, Hd, 2 * st);      // RealNVP(transform_upper=True): conditions on the lower half
+            bn_forward(2 * st);
+            coupling(Hd, 0, 2 * st + 1);  // RealNVP(transform_upper=False)
+            bn_forward(2 * st + 1);
+            f4 Pa[BT], Psh[BT];           // Affine (bijectors.py:277-298): z e^alpha + shift, log_det = sum alpha
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                pipe.gemm0(lane, bh, bl, Pa);
+                pipe.gemm1(lane, bh, bl, Psh);
+                pipe.refill1(lane);
+#pragma unroll
+                for (int bt = 0; bt < BT; ++bt) {
+                    f4* zp = reinterpret_cast<f4*>(zb + (bt * 16 + c) * ZS + 16 * t + 4 * q);
+                    f4 zv = *zp;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float aa = Pa[bt][j] * inv, sh = Psh[bt][j] * inv;
+                        zv[j] = __builtin_fmaf(zv[j], fast_exp(aa), sh);
+                        ld[bt] += aa;
+                    }
+                    *zp = zv;
+                }
+            }
+        }
+    }
+    for (int si = 0; si < (FWD ? 0 : a.S); ++si) {
         const int stg_i = a.S - 1 - si;
         {   // Affine^-1 (bijectors.py:300-315) then BatchNorm^-1 (:420-426) of layer 2*stage+1
             const float* bnA = a.bn_alpha + (int64_t)(2 * stg_i + 1) * D;
@@ -390,7 +446,7 @@ cond_flow_kernel(CondArgs a) {
         const float ldt = reduce_q(ld[bt]);
         const int64_t m = m0 + bt * 16 + c;
         if (q == 0 && m < a.M) {
-            a.log_prob[m] = -0.5f * ss - (float)D * 0.91893853320467274178f - ldt;
+            if (!FWD) a.log_prob[m] = -0.5f * ss - (float)D * 0.91893853320467274178f - ldt;
             if (a.sum_log_det) a.sum_log_det[m] = ldt;
         }
     }
@@ -418,12 +474,12 @@ int64_t cond_flow_workspace(int D, int S, int L, int U, int H) {
     return 256 + cond_image_bytes(cond_cfg(D, S, L, U, H));
 }
 
-template <int DT, int KS, int BT, int NW, bool SAVE>
+template <int DT, int KS, int BT, int NW, bool SAVE, bool FWD = false>
 static int launch_cond_variant(const CondArgs& a, hipStream_t st) {
     typedef TileStream<KS * 128 + 4, kCondG<KS>, NW, kCondNS<KS, BT, NW>> Stream;
     constexpr int D = 16 * DT;
     const size_t smem = (size_t)Stream::LDS_U4 * 16 + (size_t)NW * 16 * BT * (D + 4 + 40) * 4;
-    auto k = cond_flow_kernel<DT, KS, BT, NW, SAVE>;
+    auto k = cond_flow_kernel<DT, KS, BT, NW, SAVE, FWD>;
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int64_t per_wg = (int64_t)NW * 16 * BT;
@@ -439,6 +495,10 @@ template <int DT, int KS>
 static int launch_cond_dk(const CondArgs& a, hipStream_t st) {
     int v = g_cond_variant;
     if (v == 0) v = a.M >= 256 * 256 ? 3 : (a.M >= 256 * 128 ? 2 : 1);
+    if (a.log_prob == nullptr) {  // the sampling direction: fewer shapes (compile time)
+        if (v >= 3) return launch_cond_variant<DT, KS, 2, 8, false, true>(a, st);
+        return launch_cond_variant<DT, KS, 1, 4, false, true>(a, st);
+    }
     if (a.acts_c) {  // training forward: fewer shapes (compile time)
         if (v == 4) return launch_cond_variant<DT, KS, 4, 4, true>(a, st);
         if (v >= 2) return launch_cond_variant<DT, KS, 2, 8, true>(a, st);
@@ -483,6 +543,32 @@ int launch_cond_flow_log_prob(const float* z, const float* h, const float* W, co
     a.log_prob = log_prob; a.z0 = z0; a.sum_log_det = sum_log_det;
     a.acts_aff = acts;
     a.acts_c = acts ? acts + (int64_t)S * M * D : nullptr;
+    a.M = M; a.ldh = ldh; a.T = cfg.T; a.S = S; a.L = L; a.U = U;
+    if (D == 64) {
+        if (H == 32) return launch_cond_dk<4, 1>(a, st);
+        if (H == 64) return launch_cond_dk<4, 2>(a, st);
+        return launch_cond_dk<4, 4>(a, st);
+    }
+    if (H == 32) return launch_cond_dk<2, 1>(a, st);
+    if (H == 64) return launch_cond_dk<2, 2>(a, st);
+    return launch_cond_dk<2, 4>(a, st);
+}
+
+// ConditionalDensityEstimator.__call__(x, N = 1) with frozen statistics: omega (M, D) base draws -> z_out (M, D),
+// sum_log_det (M); the same kernel with the sampling program.
+int launch_cond_flow_forward(const float* omega, const float* h, const float* W, const float* b, const float* bn_mean,
+                             const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M, int D, int S, int L, int U,
+                             int H, int64_t ldh, int64_t ldw, void* ws, hipStream_t st) {
+    const CondCfg cfg = cond_cfg(D, S, L, U, H);
+    float* inv_scale = reinterpret_cast<float*>(ws) + 1;
+    u4* image = reinterpret_cast<u4*>(reinterpret_cast<char*>(ws) + 256);
+    int rc = launch_cond_image(W, b, ldw, cfg, ws, image, 2, st);
+    if (rc) return rc;
+    CondArgs a;
+    a.z = omega; a.h = h; a.image = image; a.inv_scale = inv_scale; a.bn_mean = bn_mean; a.bn_alpha = bn_alpha;
+    a.log_prob = nullptr; a.z0 = z_out; a.sum_log_det = sum_log_det;
+    a.acts_aff = nullptr;
+    a.acts_c = nullptr;
     a.M = M; a.ldh = ldh; a.T = cfg.T; a.S = S; a.L = L; a.U = U;
     if (D == 64) {
         if (H == 32) return launch_cond_dk<4, 1>(a, st);

@@ -108,6 +108,21 @@ __host__ __device__ inline void cond_tile_desc(const CondCfg& c, int64_t t, int6
     else cond_coupling_desc(c, so, r - c.TC, base, count);
 }
 
+// Tile t of the SAMPLING program (the flow's forward pass, density_estimator.py:374-388): stages 0..S-1, per stage
+// [RealNVP(upper) | RealNVP(lower) | Affine], every coupling layer's MLP front to back like the inverse program.
+__host__ __device__ inline void cond_tile_desc_fwd(const CondCfg& c, int64_t t, int64_t& base, int& count) {
+    const int stage = (int)(t / c.TS);
+    int64_t r = t % c.TS;
+    const int64_t so = (int64_t)stage * c.fl.stage;
+    if (r < c.TC) cond_coupling_desc(c, so, r, base, count);
+    else if (r < 2 * c.TC) cond_coupling_desc(c, so + c.fl.p_up, r - c.TC, base, count);
+    else {
+        r -= 2 * c.TC;
+        base = so + c.fl.p_up + c.fl.p_low + (r & 1) * c.D + 16 * (r >> 1);
+        count = 16;
+    }
+}
+
 // Tile t of the BACKWARD program: stages 0..S-1, per stage [RealNVP(upper) | RealNVP(lower) | Affine],
 // and inside a coupling layer the MLP back to front: output layer (weights, biases), hidden layers
 // L-1..1, layer 0.  Tiles stay paired [t net, s net] ([alpha, shift] for the Affine).

@@ -262,6 +262,9 @@ int launch_affine_backward(int dtype, const void* z, const void* params, const v
 int launch_bn_apply_backward(int dtype, const void* g_zout, const float* alpha, void* g_z, int64_t rows,
                              int D, int inverse, hipStream_t st);
 
+int launch_cond_flow_forward(const float* omega, const float* h, const float* W, const float* b, const float* bn_mean,
+                             const float* bn_alpha, float* z_out, float* sum_log_det, int64_t M, int D, int S, int L, int U,
+                             int H, int64_t ldh, int64_t ldw, void* ws, hipStream_t st);
 int launch_bn_normalize_from_moments(const float* z, const double* moments, float* z_out, float* mean_out,
                                      float* alpha_out, float* log_det, float* rstd, int64_t rows, int D, float eps,
                                      hipStream_t st);

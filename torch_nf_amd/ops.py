@@ -1169,6 +1169,33 @@ def cond_flow_log_prob_raw(z, h, weight, bias, bn_mean, bn_alpha, D, S, L, U, wa
     return lp, z0, sld
 
 
+def cond_flow_forward_raw(omega, h, weight, bias, bn_mean, bn_alpha, D, S, L, U):
+    """tnf_cond_flow_forward_f32: omega (M, D) base draws, h (M, H) = input of param_net's last Linear, weight
+    (D_params, H) / bias (D_params) of that Linear.  Returns (z (M, D), sum_log_det (M)); params never exist."""
+    dev = _lib.require_device()
+    M, H = h.shape
+    Hp = _cond_width(H)
+    if not Hp:
+        raise ValueError("conditioner width %d not supported by the fused kernel (max 128)" % H)
+    oc = _stage(omega.detach().float(), dev)
+    if oc.shape != (M, D):
+        raise ValueError("omega must be (M, D) = (%d, %d), got %s" % (M, D, tuple(oc.shape)))
+    hc = _pad_cols(_stage(h.detach(), dev), Hp)
+    wc = _pad_cols(_stage(weight.detach(), dev), Hp)
+    bc = _stage(bias.detach().float(), dev)
+    mean = _stats(bn_mean, dev)
+    alpha = _stats(bn_alpha, dev)
+    z = torch.empty((M, D), dtype=torch.float32, device=dev)
+    sld = torch.empty((M,), dtype=torch.float32, device=dev)
+    nbytes = check(lib.tnf_cond_flow_workspace_bytes(D, S, L, U, Hp))
+    ws = _workspace(nbytes, dev)
+    if M > 0:
+        check(lib.tnf_cond_flow_forward_f32(oc.data_ptr(), hc.data_ptr(), wc.data_ptr(), bc.data_ptr(), mean.data_ptr(),
+                                            alpha.data_ptr(), z.data_ptr(), sld.data_ptr(), M, D, S, L, U, Hp,
+                                            hc.stride(0), wc.stride(0), ws.data_ptr(), nbytes, _lib.stream_ptr()))
+    return z, sld
+
+
 class _CondFlowLogProbFn(torch.autograd.Function):
     """Training pair of the fused conditioner + flow: tnf_cond_flow_log_prob_fwd_f32 keeps per-layer
     activations (6 KB per context at D = 64), tnf_cond_flow_log_prob_bwd_f32 returns the gradients of
