@@ -168,6 +168,18 @@ int tnf_coupling_backward(int32_t dtype, const void* z, const void* params, cons
                           int64_t N, int32_t D, int32_t num_layers, int32_t num_units,
                           int32_t transform_upper, int32_t inverse, int64_t params_row_stride,
                           int64_t g_params_row_stride, void* stream);
+/* The same with a caller-owned workspace (tnf_coupling_backward_workspace_bytes): the shape-generic kernel -- every
+ * shape the MFMA backward does not cover: num_units > 16, odd D, float64 ... -- then reduces the parameter gradient
+ * DETERMINISTICALLY: a fixed number of persistent workgroups per parameter row, each summing its tiles in order into its
+ * own partial row, the rows added in workgroup order (bit-reproducible gradients; no float atomics).  The narrow MFMA
+ * shapes take no workspace (0 bytes) and keep their atomic tail. */
+int64_t tnf_coupling_backward_workspace_bytes(int32_t dtype, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                                              int32_t num_layers, int32_t num_units, int32_t transform_upper);
+int tnf_coupling_backward_ws(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+                             const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
+                             int64_t N, int32_t D, int32_t num_layers, int32_t num_units,
+                             int32_t transform_upper, int32_t inverse, int64_t params_row_stride,
+                             int64_t g_params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 /* g_log_det is (M_p, 1) like the forward log_det. */
 int tnf_affine_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
                         const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
@@ -232,6 +244,14 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
                      const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N,
                      int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
                      int64_t g_params_row_stride, void* stream);
+/* ... with a caller-owned workspace: deterministic reduction in the shape-generic kernel (D > 32 and the other shapes the
+ * MFMA backward does not cover), exactly as tnf_coupling_backward_ws. */
+int64_t tnf_maf_backward_workspace_bytes(int32_t dtype, int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t num_layers,
+                                         int32_t num_units);
+int tnf_maf_backward_ws(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
+                        const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N,
+                        int32_t D, int32_t num_layers, int32_t num_units, int64_t params_row_stride,
+                        int64_t g_params_row_stride, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- conditional flow, one sample per context (SNPE layout) ------------- */
 /* ConditionalDensityEstimator.log_prob(z[:, None, :], x) (conditional_density_estimator.py:101-104)

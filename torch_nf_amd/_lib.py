@@ -49,6 +49,12 @@ SIGNATURES = {
     "tnf_bn_batch_backward_apply_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "tnf_coupling_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                              _i32, _i32, _i32, _i64, _i64, _vp]),
+    "tnf_coupling_backward_workspace_bytes": (_i64, [_i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32]),
+    "tnf_coupling_backward_ws": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                                _i32, _i32, _i32, _i64, _i64, _vp, _i64, _vp]),
+    "tnf_maf_backward_workspace_bytes": (_i64, [_i32, _i64, _i64, _i64, _i32, _i32, _i32]),
+    "tnf_maf_backward_ws": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
+                                           _i32, _i64, _i64, _vp, _i64, _vp]),
     "tnf_affine_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32,
                                            _i64, _i64, _vp]),
     "tnf_bn_apply_backward": (ctypes.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),

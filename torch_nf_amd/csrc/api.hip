@@ -274,10 +274,10 @@ int tnf_bn_batch_forward_f32(const float* z, float* z_out, float* mean_out, floa
                                    as_stream(stream));
 }
 
-int tnf_coupling_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+static int coupling_backward_impl(int32_t dtype, const void* z, const void* params, const void* g_z_out,
                           const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
                           int64_t N, int32_t D, int32_t L, int32_t U, int32_t upper, int32_t inverse,
-                          int64_t pstride, int64_t gpstride, void* stream) {
+                          int64_t pstride, int64_t gpstride, void* stream, void* ws, int64_t ws_bytes) {
     if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_coupling_backward: dtype %d", dtype);
     if (M < 1 || N < 0 || D < 2 || L < 1 || U < 1 || (M_p != 1 && M_p != M))
         return fail(TNF_EINVAL, "tnf_coupling_backward: M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", (long long)M,
@@ -294,8 +294,38 @@ int tnf_coupling_backward(int32_t dtype, const void* z, const void* params, cons
         return launch_coupling_backward_mfma((const float*)z, (const float*)params, (const float*)g_z_out,
                                              (const float*)g_log_det, (float*)g_z, (float*)g_params, M, M_p, N,
                                              D, L, U, upper, inverse, pstride, gpstride, as_stream(stream));
+    // (a caller that sized the workspace for the MFMA kernel -- 0 bytes -- but lands here, e.g. through unaligned
+    // pointers, gets the legacy atomic reduction rather than an error)
+    if (ws_bytes == 0 && coupling_backward_workspace(dtype, M, M_p, N, D, L, U, upper) > 0) ws_bytes = -1;
     return launch_coupling_backward(dtype, z, params, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
-                                    upper, inverse, pstride, gpstride, as_stream(stream));
+                                    upper, inverse, pstride, gpstride, as_stream(stream), ws, ws_bytes);
+}
+
+int tnf_coupling_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+                          const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
+                          int64_t N, int32_t D, int32_t L, int32_t U, int32_t upper, int32_t inverse,
+                          int64_t pstride, int64_t gpstride, void* stream) {
+    return coupling_backward_impl(dtype, z, params, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U, upper, inverse,
+                                  pstride, gpstride, stream, nullptr, -1);
+}
+
+int64_t tnf_coupling_backward_workspace_bytes(int32_t dtype, int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t L,
+                                              int32_t U, int32_t upper) {
+    if ((dtype != TNF_F32 && dtype != TNF_F64) || M < 1 || N < 0 || D < 2 || L < 1 || U < 1 || (M_p != 1 && M_p != M))
+        return fail(TNF_EINVAL, "tnf_coupling_backward_workspace_bytes: dtype=%d M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", dtype,
+                    (long long)M, (long long)M_p, (long long)N, D, L, U);
+    if (dtype == TNF_F32 && !g_force_generic && mfma_supported(D, L, U) && N >= 16) return 0;  // the MFMA kernel takes none
+    return coupling_backward_workspace(dtype, M, M_p, N, D, L, U, upper);
+}
+
+int tnf_coupling_backward_ws(int32_t dtype, const void* z, const void* params, const void* g_z_out,
+                             const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p,
+                             int64_t N, int32_t D, int32_t L, int32_t U, int32_t upper, int32_t inverse,
+                             int64_t pstride, int64_t gpstride, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace))
+        return fail(TNF_EINVAL, "tnf_coupling_backward_ws: workspace %p of %lld bytes", workspace, (long long)workspace_bytes);
+    return coupling_backward_impl(dtype, z, params, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U, upper, inverse,
+                                  pstride, gpstride, stream, workspace, workspace_bytes);
 }
 
 int tnf_affine_backward(int32_t dtype, const void* z, const void* params, const void* g_z_out,
@@ -512,9 +542,9 @@ int tnf_maf_inverse_alpha(int32_t dtype, const void* z, const void* params, cons
     return launch_maf(dtype, z, params, masks, z_out, log_det, M_z, M_p, N, D, L, U, 1, pstride, as_stream(stream), alpha_out);
 }
 
-int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
+static int maf_backward_impl(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
                      const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D,
-                     int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* stream) {
+                     int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* stream, void* ws, int64_t ws_bytes) {
     if (dtype != TNF_F32 && dtype != TNF_F64) return fail(TNF_EINVAL, "tnf_maf_backward: dtype %d", dtype);
     if (M < 1 || N < 0 || D < 1 || L < 1 || U < 1 || (M_p != 1 && M_p != M))
         return fail(TNF_EINVAL, "tnf_maf_backward: M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", (long long)M,
@@ -529,7 +559,32 @@ int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const voi
                                         (const float*)g_log_det, (float*)g_z, (float*)g_params, M, M_p, N, D, L, U,
                                         pstride, gpstride, as_stream(stream));
     return launch_maf_backward(dtype, z, params, masks, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
-                               pstride, gpstride, as_stream(stream));
+                               pstride, gpstride, as_stream(stream), ws, ws_bytes);
+}
+
+int tnf_maf_backward(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
+                     const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                     int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* stream) {
+    return maf_backward_impl(dtype, z, params, masks, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U, pstride,
+                             gpstride, stream, nullptr, -1);
+}
+
+int64_t tnf_maf_backward_workspace_bytes(int32_t dtype, int64_t M, int64_t M_p, int64_t N, int32_t D, int32_t L, int32_t U) {
+    if ((dtype != TNF_F32 && dtype != TNF_F64) || M < 1 || N < 0 || D < 1 || L < 1 || U < 1 || (M_p != 1 && M_p != M))
+        return fail(TNF_EINVAL, "tnf_maf_backward_workspace_bytes: dtype=%d M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", dtype,
+                    (long long)M, (long long)M_p, (long long)N, D, L, U);
+    if (dtype == TNF_F32 && !g_force_generic && maf_bwd_mfma_supported(D, L, U)) return 0;  // the MFMA kernel takes none
+    return maf_backward_workspace(dtype, M, M_p, N, D, L, U);
+}
+
+int tnf_maf_backward_ws(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,
+                        const void* g_log_det, void* g_z, void* g_params, int64_t M, int64_t M_p, int64_t N, int32_t D,
+                        int32_t L, int32_t U, int64_t pstride, int64_t gpstride, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+    if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace))
+        return fail(TNF_EINVAL, "tnf_maf_backward_ws: workspace %p of %lld bytes", workspace, (long long)workspace_bytes);
+    return maf_backward_impl(dtype, z, params, masks, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U, pstride,
+                             gpstride, stream, workspace, workspace_bytes);
 }
 
 int tnf_cond_flow_supported(int32_t D, int32_t S, int32_t L, int32_t U, int32_t H) {

@@ -39,23 +39,34 @@ coupling_backward_kernel(const T* __restrict__ z, const T* __restrict__ params,
                          const T* __restrict__ g_zout, const T* __restrict__ g_ld,
                          T* __restrict__ g_z, T* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N,
                          int D, int L, int U, int upper, int inverse, int64_t pstride, int64_t gpstride,
-                         int TS, int W) {
+                         int TS, int W, T* __restrict__ partials, int64_t prow) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x;
     const int64_t m = grid_m();
     if (m >= M) return;
-    const int64_t n0 = (int64_t)blockIdx.x * TS;
-    const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
     const int h = D / 2;
     const CouplingDims cd = coupling_dims(D, upper);
     const int c_off = upper ? 0 : h, t_off = upper ? h : 0;
     const int64_t mp = Mp == 1 ? 0 : m;
+    const T* p0 = params + mp * pstride;
+    // Where this workgroup's parameter-gradient contributions go.  Deterministic mode (`partials`): its own row of the
+    // partial buffer -- every element is owned by one thread (the loops below map an index to the same thread for every
+    // tile), stored on the workgroup's first tile and read-modify-written afterwards; backward_reduce_kernel adds the
+    // rows in workgroup order.  With one workgroup per parameter row the row of g_params itself is that buffer.
+    // Legacy mode (no workspace): one atomic per parameter per tile, summation order left to the hardware.
+    const bool det = partials != nullptr || prow < 0;
+    T* gp0 = partials ? partials + (m * gridDim.x + blockIdx.x) * prow : g_params + mp * gpstride;
+    const bool rmw_always = partials == nullptr;  // g_params accumulates (the caller zeroed it)
+    const int64_t ntiles = (N + TS - 1) / TS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool first = tile == blockIdx.x && !rmw_always;
+    const int64_t n0 = tile * TS;
+    const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
     const T* zt = z + (m * N + n0) * D;
     const T* gzo = g_zout + (m * N + n0) * D;
     T* gz = g_z + (m * N + n0) * D;
-    const T* p0 = params + mp * pstride;
-    T* gp0 = g_params + mp * gpstride;
+    __syncthreads();  // the previous tile's readers are done with the activation planes
     const int64_t plane = (int64_t)TS * W;
     // act(net, l): l = 0..L ; act(*, 0) is x for both nets
     T* actx = smem;                                   // [TS][W]
@@ -163,8 +174,13 @@ coupling_backward_kernel(const T* __restrict__ z, const T* __restrict__ params,
                 a_t += xt[i * W + k] * dtc[i * W + o];
                 a_s += xs[i * W + k] * dsc[i * W + o];
             }
-            atomicAdd(gwt + idx, a_t);
-            atomicAdd(gws + idx, a_s);
+            if (det) {
+                gwt[idx] = first ? a_t : gwt[idx] + a_t;
+                gws[idx] = first ? a_s : gws[idx] + a_s;
+            } else {
+                atomicAdd(gwt + idx, a_t);
+                atomicAdd(gws + idx, a_s);
+            }
         }
         for (int o = tid; o < dout; o += 256) {
             T a_t = 0, a_s = 0;
@@ -172,8 +188,13 @@ coupling_backward_kernel(const T* __restrict__ z, const T* __restrict__ params,
                 a_t += dtc[i * W + o];
                 a_s += dsc[i * W + o];
             }
-            atomicAdd(gbt + o, a_t);
-            atomicAdd(gbs + o, a_s);
+            if (det) {
+                gbt[o] = first ? a_t : gbt[o] + a_t;
+                gbs[o] = first ? a_s : gbs[o] + a_s;
+            } else {
+                atomicAdd(gbt + o, a_t);
+                atomicAdd(gbs + o, a_s);
+            }
         }
         // delta of the previous layer (or of x)
         if (l > 0) {
@@ -202,14 +223,70 @@ coupling_backward_kernel(const T* __restrict__ z, const T* __restrict__ params,
         __syncthreads();
         cur ^= 1;
     }
+    }  // tiles
+}
+
+// g_params[mp][i] += sum over the G partial rows of parameter row mp, in workgroup order (deterministic)
+template <typename T>
+__global__ void __launch_bounds__(256)
+backward_reduce_kernel(const T* __restrict__ partials, T* __restrict__ g_params, int64_t rows, int G, int64_t P,
+                       int64_t gpstride) {
+    const int64_t mp = grid_m();
+    if (mp >= rows) return;
+    const T* src = partials + mp * G * P;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+        T acc = 0;
+        for (int b = 0; b < G; ++b) acc += src[(int64_t)b * P + i];
+        g_params[mp * gpstride + i] += acc;
+    }
+}
+int launch_backward_reduce(int dtype, const void* partials, void* g_params, int64_t rows, int G, int64_t P,
+                           int64_t gpstride, hipStream_t st) {
+    const dim3 grid = grid_xm((P + 255) / 256, rows);
+    if (dtype == TNF_F32)
+        hipLaunchKernelGGL(backward_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)partials, (float*)g_params, rows, G, P, gpstride);
+    else
+        hipLaunchKernelGGL(backward_reduce_kernel<double>, grid, dim3(256), 0, st, (const double*)partials, (double*)g_params, rows, G, P, gpstride);
+    return check_launch("backward_reduce");
+}
+
+// Deterministic geometry of the shape-generic backward kernels: G persistent workgroups per parameter row.  One shared
+// row: the M sample batches are one batch (the tensors are contiguous); per-context rows: G = 1 once there are enough
+// contexts to fill the chip, and a row's only workgroup then writes g_params itself.
+void backward_det_geometry(int64_t M, int64_t Mp, int64_t tiles_per_m, int* G, int64_t* rows) {
+    const int64_t target = 512;
+    int64_t g = Mp == 1 ? target : (target + M - 1) / M;
+    const int64_t tiles = Mp == 1 ? tiles_per_m * M : tiles_per_m;
+    if (g > tiles) g = tiles;
+    if (g < 1) g = 1;
+    *G = (int)g;
+    *rows = Mp == 1 ? 1 : M;
+}
+
+int64_t coupling_backward_workspace(int dtype, int64_t M, int64_t Mp, int64_t N, int D, int L, int U, int upper) {
+    const size_t esz = dtype == TNF_F64 ? 8 : 4;
+    const CouplingDims cd = coupling_dims(D, upper);
+    int W = cd.d_in > cd.d_out ? cd.d_in : cd.d_out;
+    if (U > W) W = U;
+    int64_t TS = (int64_t)(96 * 1024) / (int64_t)((size_t)(1 + 2 * L + 2 + 4) * W * esz);
+    if (TS > 64) TS = 64;
+    if (TS < 1) TS = 1;
+    int G;
+    int64_t rows;
+    backward_det_geometry(M, Mp, ((N > 0 ? N : 1) + TS - 1) / TS, &G, &rows);  // (an upper bound: TS shrinks with N)
+    return G > 1 ? rows * G * coupling_num_params(D, L, U, upper) * (int64_t)esz : 0;
 }
 
 int launch_coupling_backward(int dtype, const void* z, const void* params, const void* g_zout,
                              const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp,
                              int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
-                             int64_t gpstride, hipStream_t st) {
+                             int64_t gpstride, hipStream_t st, void* ws, int64_t ws_bytes) {
     const CouplingDims cd = coupling_dims(D, upper);
     diag_count(TNF_DIAG_BWD_GENERIC);
+    if (ws_bytes >= 0 && Mp == 1 && M > 1) {  // deterministic mode, one shared row: one batch of M * N samples
+        N *= M;
+        M = 1;
+    }
     int W = cd.d_in > cd.d_out ? cd.d_in : cd.d_out;
     if (U > W) W = U;
     const size_t esz = dtype == TNF_F64 ? 8 : 4;
@@ -221,23 +298,43 @@ int launch_coupling_backward(int dtype, const void* z, const void* params, const
     const size_t smem = (size_t)planes * TS * W * esz;
     if (smem > 160 * 1024)
         return fail(TNF_EUNSUPPORTED, "coupling_backward: layer width %d needs %zu B of LDS", W, smem);
-    const int64_t tiles = (N + TS - 1) / TS;
+    int64_t tiles = (N + TS - 1) / TS;
     if (tiles > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "coupling_backward: grid too large");
+    // ws_bytes < 0: legacy mode (atomics).  Otherwise deterministic: G workgroups per parameter row, partial rows in ws
+    void* partials = nullptr;
+    int64_t prow = 0;
+    int G = 1;
+    int64_t rows = 0;
+    if (ws_bytes >= 0) {
+        backward_det_geometry(M, Mp, tiles, &G, &rows);
+        prow = coupling_num_params(D, L, U, upper);
+        if (G > 1) {
+            if (!ws || ws_bytes < rows * G * prow * (int64_t)esz)
+                return fail(TNF_EWORKSPACE, "coupling_backward: workspace %lld < %lld", (long long)ws_bytes,
+                            (long long)(rows * G * prow * (int64_t)esz));
+            partials = ws;
+        } else {
+            prow = -1;  // the row's only workgroup accumulates in g_params itself
+        }
+        tiles = G;
+    }
     const dim3 grid = grid_xm(tiles, M);
     if (dtype == TNF_F32) {
         auto k = coupling_backward_kernel<float>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const float*)z, (const float*)params,
                            (const float*)g_zout, (const float*)g_ld, (float*)g_z, (float*)g_params, M, Mp, N, D,
-                           L, U, upper, inverse, pstride, gpstride, (int)TS, W);
+                           L, U, upper, inverse, pstride, gpstride, (int)TS, W, (float*)partials, prow);
     } else {
         auto k = coupling_backward_kernel<double>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const double*)z, (const double*)params,
                            (const double*)g_zout, (const double*)g_ld, (double*)g_z, (double*)g_params, M, Mp,
-                           N, D, L, U, upper, inverse, pstride, gpstride, (int)TS, W);
+                           N, D, L, U, upper, inverse, pstride, gpstride, (int)TS, W, (double*)partials, prow);
     }
-    return check_launch("coupling_backward");
+    const int rc = check_launch("coupling_backward");
+    if (rc || !partials) return rc;
+    return launch_backward_reduce(dtype, partials, g_params, rows, G, prow, gpstride, st);
 }
 
 // ---------------------------------------------------------------------------

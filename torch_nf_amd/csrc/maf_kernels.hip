@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(256)
 maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const T* __restrict__ masks,
                     const T* __restrict__ g_zout, const T* __restrict__ g_ld, T* __restrict__ g_z,
                     T* __restrict__ g_params, int64_t M, int64_t Mp, int64_t N, int D, int L, int U,
-                    int64_t pstride, int64_t gpstride, int TS, int W, int lacc, int lw, int P) {
+                    int64_t pstride, int64_t gpstride, int TS, int W, int lacc, int lw, int P,
+                    T* __restrict__ partials, int det) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x;
@@ -188,7 +189,10 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
     if (m >= M) return;
     const int64_t mp = Mp == 1 ? 0 : m;
     const T* p0 = params + mp * pstride;
-    T* gp0 = g_params + mp * gpstride;
+    // deterministic mode (det): contributions go to this workgroup's row of `partials` (backward_reduce_kernel adds the rows
+    // in workgroup order) or, with one workgroup per parameter row (partials == NULL), straight into g_params -- every
+    // element owned by one thread, no atomics (see coupling_backward_kernel)
+    T* gp0 = partials ? partials + (m * gridDim.x + blockIdx.x) * (int64_t)P : g_params + mp * gpstride;
     const int64_t plane = (int64_t)TS * W;
     T* actx = smem;
     T* acts = smem + plane;                       // [2][L][TS][W]
@@ -215,6 +219,7 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
     const T* pw = lw ? wl : p0;  // weights as the loops below read them (masked already when lw)
     const int64_t ntiles = (N + TS - 1) / TS;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool first = det && partials != nullptr && tile == blockIdx.x;  // partial rows start from this tile's value
     const int64_t n0 = tile * TS;
     const int ts = (int)((N - n0) < (int64_t)TS ? (N - n0) : (int64_t)TS);
     const T* zt = z + (m * N + n0) * D;
@@ -308,10 +313,16 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
                 if (lacc) {  // idx is owned by this thread for every tile of the workgroup
                     gacc[off + idx] += mv * am;
                     gacc[off + nw + idx] += mv * aa;
+                } else if (det) {
+                    gwm[idx] = first ? mv * am : gwm[idx] + mv * am;
+                    gwa[idx] = first ? mv * aa : gwa[idx] + mv * aa;
                 } else {
                     atomicAdd(gwm + idx, mv * am);
                     atomicAdd(gwa + idx, mv * aa);
                 }
+            } else if (first && !lacc) {
+                gwm[idx] = 0;
+                gwa[idx] = 0;
             }
         }
         if (l > 0) {
@@ -358,17 +369,35 @@ maf_backward_kernel(const T* __restrict__ z, const T* __restrict__ params, const
         const bool own = Mp > 1 && gridDim.x == 1;  // this workgroup is the only writer of its context's row
         for (int i = tid; i < P; i += 256) {
             const T v = gacc[i];
-            if (own) gp0[i] = v;
+            if (own || (det && partials)) gp0[i] = v;
+            else if (det) gp0[i] += v;  // one workgroup per row, g_params accumulates
             else if (v != (T)0) atomicAdd(gp0 + i, v);
         }
     }
 }
 
+int64_t maf_backward_workspace(int dtype, int64_t M, int64_t Mp, int64_t N, int D, int L, int U) {
+    const size_t esz = dtype == TNF_F64 ? 8 : 4;
+    int W;
+    size_t smem;
+    const int TS = maf_tile(D, U, L, esz, 1 + 2 * L + 2 + 4, N > 0 ? N : 1, &W, &smem);
+    int G;
+    int64_t rows;
+    backward_det_geometry(M, Mp, ((N > 0 ? N : 1) + TS - 1) / TS, &G, &rows);
+    const int64_t P = 2 * (2 * (int64_t)D * U + (int64_t)(L - 1) * U * U);
+    return G > 1 ? rows * G * P * (int64_t)esz : 0;
+}
+
 int launch_maf_backward(int dtype, const void* z, const void* params, const void* masks, const void* g_zout,
                         const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N, int D, int L,
-                        int U, int64_t pstride, int64_t gpstride, hipStream_t st) {
+                        int U, int64_t pstride, int64_t gpstride, hipStream_t st, void* ws, int64_t ws_bytes) {
     const size_t esz = dtype == TNF_F64 ? 8 : 4;
     diag_count(TNF_DIAG_MAF_BWD_GENERIC);
+    const int det = ws_bytes >= 0;
+    if (det && Mp == 1 && M > 1) {  // one shared row: one batch of M * N samples
+        N *= M;
+        M = 1;
+    }
     int W;
     size_t smem;
     const int TS = maf_tile(D, U, L, esz, 1 + 2 * L + 2 + 4, N, &W, &smem);
@@ -389,21 +418,37 @@ int launch_maf_backward(int dtype, const void* z, const void* params, const void
             if (tiles > cap) tiles = cap;
         }
     }
+    void* partials = nullptr;
+    int G = 1;
+    int64_t rows = 0;
+    if (det) {  // G persistent workgroups per parameter row, their contributions added in workgroup order
+        backward_det_geometry(M, Mp, tiles, &G, &rows);
+        if (G > 1) {
+            if (!ws || ws_bytes < rows * G * P * (int64_t)esz)
+                return fail(TNF_EWORKSPACE, "maf_backward: workspace %lld < %lld", (long long)ws_bytes,
+                            (long long)(rows * G * P * (int64_t)esz));
+            partials = ws;
+        }
+        tiles = G;
+    }
     const dim3 grid = grid_xm(tiles, M);
     if (dtype == TNF_F32) {
         auto k = maf_backward_kernel<float>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const float*)z, (const float*)params, (const float*)masks,
                            (const float*)g_zout, (const float*)g_ld, (float*)g_z, (float*)g_params, M, Mp, N, D, L,
-                           U, pstride, gpstride, TS, W, lacc, lw, (int)P);
+                           U, pstride, gpstride, TS, W, lacc, lw, (int)P, (float*)partials, det);
     } else {
         auto k = maf_backward_kernel<double>;
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(k, grid, dim3(256), smem, st, (const double*)z, (const double*)params,
                            (const double*)masks, (const double*)g_zout, (const double*)g_ld, (double*)g_z,
-                           (double*)g_params, M, Mp, N, D, L, U, pstride, gpstride, TS, W, lacc, lw, (int)P);
+                           (double*)g_params, M, Mp, N, D, L, U, pstride, gpstride, TS, W, lacc, lw, (int)P,
+                           (double*)partials, det);
     }
-    return check_launch("maf_backward");
+    const int rc = check_launch("maf_backward");
+    if (rc || !partials) return rc;
+    return launch_backward_reduce(dtype, partials, g_params, rows, G, P, gpstride, st);
 }
 
 }  // namespace tnf

@@ -223,7 +223,13 @@ int launch_bn_batch_forward(const float* z, float* z_out, float* mean_out, float
 int launch_coupling_backward(int dtype, const void* z, const void* params, const void* g_zout,
                              const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp,
                              int64_t N, int D, int L, int U, int upper, int inverse, int64_t pstride,
-                             int64_t gpstride, hipStream_t st);
+                             int64_t gpstride, hipStream_t st, void* ws = nullptr, int64_t ws_bytes = -1);
+// ws_bytes >= 0: deterministic reduction of the parameter gradient (partial rows in ws, added in workgroup order)
+int64_t coupling_backward_workspace(int dtype, int64_t M, int64_t Mp, int64_t N, int D, int L, int U, int upper);
+void backward_det_geometry(int64_t M, int64_t Mp, int64_t tiles_per_m, int* G, int64_t* rows);
+int launch_backward_reduce(int dtype, const void* partials, void* g_params, int64_t rows, int G, int64_t P,
+                           int64_t gpstride, hipStream_t st);
+int64_t maf_backward_workspace(int dtype, int64_t M, int64_t Mp, int64_t N, int D, int L, int U);
 // arguments of the MFMA backward kernel (coupling_bwd_mfma.hip)
 struct BwdArgs {
     const float* z;
@@ -332,7 +338,7 @@ int launch_maf(int dtype, const void* z, const void* params, const void* masks, 
                int64_t Mz, int64_t Mp, int64_t N, int D, int L, int U, int inverse, int64_t pstride, hipStream_t st, void* alpha_out = nullptr);
 int launch_maf_backward(int dtype, const void* z, const void* params, const void* masks, const void* g_zout,
                         const void* g_ld, void* g_z, void* g_params, int64_t M, int64_t Mp, int64_t N, int D, int L,
-                        int U, int64_t pstride, int64_t gpstride, hipStream_t st);
+                        int U, int64_t pstride, int64_t gpstride, hipStream_t st, void* ws = nullptr, int64_t ws_bytes = -1);
 int launch_base_log_density(int dtype, const void* omega, double* out, int64_t rows, int D, hipStream_t st);
 
 }  // namespace tnf

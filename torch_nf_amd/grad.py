@@ -2,13 +2,24 @@
 
 Each function calls one HIP backward kernel through the C ABI (tnf_*_backward); the
 activations are recomputed inside the kernel from the saved layer input, so autograd keeps
-only z and the parameters alive.  Parameter gradients are reduced over the samples with
-float atomics in the kernel.
+only z and the parameters alive.  Parameter gradients are reduced over the samples inside the kernels: the
+shape-generic coupling / MAF kernels deterministically (fixed workgroups, partial rows added in order, a workspace
+from tnf_*_backward_workspace_bytes), the narrow MFMA layer kernels with one float atomic per parameter per workgroup.
 """
 import torch
 
 from . import _lib
 from ._lib import lib, check
+
+
+class _OpsProxy(object):  # ops imports this module lazily; the workspace cache lives there
+    def __getattr__(self, name):
+        from . import ops as _ops
+
+        return getattr(_ops, name)
+
+
+ops = _OpsProxy()
 
 
 def _dev(t, dev):
@@ -34,9 +45,13 @@ def coupling_backward(z, params, z_out, g_z, g_ld, D, L, U, upper, inverse):
     gp = torch.zeros(tuple(params.shape), dtype=params.dtype, device=dev)
     pstride = pc.stride(0) if Mp > 1 else max(pc.stride(0), pc.shape[1])
     if N > 0:
-        check(lib.tnf_coupling_backward(code, zc.data_ptr(), pc.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
-                                        gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, L, U, int(upper), int(inverse),
-                                        pstride, gp.shape[1], _lib.stream_ptr()))
+        # with a workspace the shape-generic kernel (num_units > 16, odd D, float64 ...) reduces deterministically
+        nbytes = check(lib.tnf_coupling_backward_workspace_bytes(code, M, Mp, N, D, L, U, int(upper)))
+        ws = ops._workspace(nbytes, dev) if nbytes else None
+        check(lib.tnf_coupling_backward_ws(code, zc.data_ptr(), pc.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
+                                           gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, L, U, int(upper), int(inverse),
+                                           pstride, gp.shape[1], ws.data_ptr() if nbytes else None, nbytes,
+                                           _lib.stream_ptr()))
     if Mz != M:
         gz = gz.sum(0, keepdim=True)
     return (gz if home_z == dev else gz.to(home_z)), (gp if home_p == dev else gp.to(home_p))
@@ -121,9 +136,11 @@ def maf_backward(z, params, masks, g_z, g_ld, D, L, U):
     gp = torch.zeros(tuple(params.shape), dtype=params.dtype, device=dev)
     pstride = pc.stride(0) if Mp > 1 else max(pc.stride(0), pc.shape[1])
     if N > 0:
-        check(lib.tnf_maf_backward(code, zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
-                                   gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, L, U, pstride, gp.shape[1],
-                                   _lib.stream_ptr()))
+        nbytes = check(lib.tnf_maf_backward_workspace_bytes(code, M, Mp, N, D, L, U))
+        ws = ops._workspace(nbytes, dev) if nbytes else None
+        check(lib.tnf_maf_backward_ws(code, zc.data_ptr(), pc.data_ptr(), mk.data_ptr(), g_zo.data_ptr(), g_l.data_ptr(),
+                                      gz.data_ptr(), gp.data_ptr(), M, Mp, N, D, L, U, pstride, gp.shape[1],
+                                      ws.data_ptr() if nbytes else None, nbytes, _lib.stream_ptr()))
     if Mz != M:
         gz = gz.sum(0, keepdim=True)
     return (gz if home_z == dev else gz.to(home_z)), (gp if home_p == dev else gp.to(home_p))
