@@ -793,7 +793,9 @@ def test_wide_shape_backward_is_reproducible(tnf, oracle, kind, M, Mp, N):
     wz = torch.tensor(rng.normal(0, 1, (Mo, N, D))).float()
     wl = torch.tensor(rng.normal(0, 1, (Mo, N))).float()
     lib = tnf._lib.lib
-    fam = tnf._lib.DIAG_BWD_GENERIC if kind == "coupling" else tnf._lib.DIAG_MAF_BWD_GENERIC
+    # one shared row at num_units = 64: the two-pass MFMA backward (coupling_wide_bwd.hip); per-context rows and MAF: the
+    # shape-generic kernels -- both without atomics
+    fam = (tnf._lib.DIAG_BWD_WIDE if Mp == 1 else tnf._lib.DIAG_BWD_GENERIC) if kind == "coupling" else tnf._lib.DIAG_MAF_BWD_GENERIC
     before = lib.tnf_diag_launch_count(fam)
     grads = []
     for _ in range(3):
@@ -801,7 +803,7 @@ def test_wide_shape_backward_is_reproducible(tnf, oracle, kind, M, Mp, N):
         zo, ld = run(z, p)
         ((zo * wz.cuda()).sum() + (ld * wl.cuda()).sum()).backward()
         grads.append((p.grad.clone(), z.grad.clone()))
-    assert lib.tnf_diag_launch_count(fam) == before + 3  # the shape-generic kernel it is
+    assert lib.tnf_diag_launch_count(fam) == before + 3  # the kernel family meant
     for gp, gz in grads[1:]:
         assert torch.equal(gp, grads[0][0]) and torch.equal(gz, grads[0][1])
     n = min(N, 300)  # correctness on a slice the CPU oracle finishes quickly
@@ -812,4 +814,43 @@ def test_wide_shape_backward_is_reproducible(tnf, oracle, kind, M, Mp, N):
     zo, ld = run(z, p)
     ((zo * wz[:, :n].cuda()).sum() + (ld * wl[:, :n].cuda()).sum()).backward()
     grad_err("wide / MAF D=64 generic backward: d params", p.grad, pr.grad, 1.2e-6)  # 4 x the 2.7e-7 / 1.9e-7 measured
-    grad_err("wide / MAF D=64 generic backward: d z", z.grad, zr.grad, 8e-7)
+    grad_err("wide / MAF D=64 generic backward: d z", z.grad, zr.grad, 3e-6)  # (6.8e-7 with the wide MFMA kernel)
+
+
+@pytest.mark.parametrize("D,L,U,upper,inverse,M,N", [
+    (64, 2, 64, True, True, 1, 1000), (64, 2, 20, False, False, 3, 333), (128, 1, 33, True, True, 1, 70),
+    (24, 3, 32, False, True, 2, 50), (40, 2, 48, True, False, 1, 17), (64, 2, 64, True, True, 1, (1 << 18) + 77),
+])
+def test_wide_shape_backward_mfma(tnf, oracle, D, L, U, upper, inverse, M, N):
+    """Round 3: the two-pass fp32-MFMA backward of the wide coupling shapes (coupling_wide_bwd.hip; num_units up to 64, one
+    shared parameter row) against torch autograd over the oracle and against the shape-generic kernel it replaces --
+    padded feature / unit tiles, both directions, several sample batches of one row, and a batch that crosses the 2^18-sample
+    chunk of its record workspace."""
+    rng = np.random.RandomState(D + U + N)
+    layer = tnf.RealNVP(D, L, U, transform_upper=upper)
+    p0 = torch.tensor(rng.normal(0, 0.05, (1, layer.count_num_params()))).float()
+    z0 = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+    wz = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+    wl = torch.tensor(rng.normal(0, 1, (M, N))).float()
+    run = (lambda z_, p_: layer.inverse_and_log_det(z_, p_)) if inverse else (lambda z_, p_: layer(z_, p_))
+    lib = tnf._lib.lib
+    res = []
+    for generic in (0, 1):
+        before = lib.tnf_diag_launch_count(tnf._lib.DIAG_BWD_WIDE)
+        lib.tnf_set_option(tnf._lib.OPT_FORCE_GENERIC, generic)
+        try:
+            p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
+            zo, ld = run(z, p)
+            ((zo * wz.cuda()).sum() + (ld * wl.cuda()).sum()).backward()
+            res.append((p.grad.cpu(), z.grad.cpu()))
+        finally:
+            lib.tnf_set_option(tnf._lib.OPT_FORCE_GENERIC, 0)
+        assert lib.tnf_diag_launch_count(tnf._lib.DIAG_BWD_WIDE) - before == 1 - generic
+    grad_err("wide MFMA backward vs the generic kernel: d params", res[0][0], res[1][0], 2e-6)  # 4 x 5.0e-7 / 1.1e-6 measured
+    grad_err("wide MFMA backward vs the generic kernel: d z", res[0][1], res[1][1], 4.4e-6)
+    if N <= 1000:
+        pr, zr = p0.clone().requires_grad_(), z0.clone().requires_grad_()
+        zo, ld = oracle.coupling(zr, pr, D, L, U, upper, inverse)
+        ((zo * wz).sum() + (ld * wl).sum()).backward()
+        grad_err("wide MFMA backward vs the oracle: d params", res[0][0], pr.grad, 1.1e-6)  # 4 x 2.6e-7 / 6.3e-7 measured
+        grad_err("wide MFMA backward vs the oracle: d z", res[0][1], zr.grad, 2.6e-6)

@@ -294,6 +294,12 @@ static int coupling_backward_impl(int32_t dtype, const void* z, const void* para
         return launch_coupling_backward_mfma((const float*)z, (const float*)params, (const float*)g_z_out,
                                              (const float*)g_log_det, (float*)g_z, (float*)g_params, M, M_p, N,
                                              D, L, U, upper, inverse, pstride, gpstride, as_stream(stream));
+    // the wide shapes (num_units up to 64) with one shared parameter row: two-pass MFMA backward (coupling_wide_bwd.hip)
+    if (dtype == TNF_F32 && !g_force_generic && M_p == 1 && ws && wide_bwd_supported(D, L, U) && aligned16(z) &&
+        aligned16(g_z_out) && aligned16(g_z) && aligned16(ws) && ws_bytes >= wide_bwd_workspace(M * N, D, L, U))
+        return launch_coupling_backward_wide((const float*)z, (const float*)params, (const float*)g_z_out,
+                                             (const float*)g_log_det, (float*)g_z, (float*)g_params, M * N, D, L, U, upper,
+                                             inverse, gpstride, ws, as_stream(stream));
     // (a caller that sized the workspace for the MFMA kernel -- 0 bytes -- but lands here, e.g. through unaligned
     // pointers, gets the legacy atomic reduction rather than an error)
     if (ws_bytes == 0 && coupling_backward_workspace(dtype, M, M_p, N, D, L, U, upper) > 0) ws_bytes = -1;
@@ -315,7 +321,12 @@ int64_t tnf_coupling_backward_workspace_bytes(int32_t dtype, int64_t M, int64_t 
         return fail(TNF_EINVAL, "tnf_coupling_backward_workspace_bytes: dtype=%d M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", dtype,
                     (long long)M, (long long)M_p, (long long)N, D, L, U);
     if (dtype == TNF_F32 && !g_force_generic && mfma_supported(D, L, U) && N >= 16) return 0;  // the MFMA kernel takes none
-    return coupling_backward_workspace(dtype, M, M_p, N, D, L, U, upper);
+    const int64_t gen = coupling_backward_workspace(dtype, M, M_p, N, D, L, U, upper);
+    if (dtype == TNF_F32 && !g_force_generic && M_p == 1 && wide_bwd_supported(D, L, U)) {
+        const int64_t wide = wide_bwd_workspace(M * N, D, L, U);  // records of the two-pass MFMA backward + partial rows
+        return wide > gen ? wide : gen;
+    }
+    return gen;
 }
 
 int tnf_coupling_backward_ws(int32_t dtype, const void* z, const void* params, const void* g_z_out,

@@ -113,6 +113,12 @@ int launch_coupling_mfma(const MfmaLayerArgs& a, hipStream_t st);
 bool wide_supported(int D, int L, int U);
 int64_t wide_image_floats(int D, int L, int U);
 int launch_coupling_wide(const MfmaLayerArgs& a, hipStream_t st);
+// MFMA backward of the wide shapes (coupling_wide_bwd.hip): one shared parameter row, N = all samples of the call
+bool wide_bwd_supported(int D, int L, int U);
+int64_t wide_bwd_workspace(int64_t N, int D, int L, int U);
+int launch_coupling_backward_wide(const float* z, const float* params, const float* g_zout, const float* g_ld, float* g_z,
+                                  float* g_params, int64_t N, int D, int L, int U, int upper, int inverse,
+                                  int64_t gpstride, void* ws, hipStream_t st);
 int launch_wide_images(const float* params, float* images, int64_t Mp, int D, int S, int L, int U,
                        int64_t pstride, hipStream_t st);
 
