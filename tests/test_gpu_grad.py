@@ -793,9 +793,12 @@ def test_wide_shape_backward_is_reproducible(tnf, oracle, kind, M, Mp, N):
     wz = torch.tensor(rng.normal(0, 1, (Mo, N, D))).float()
     wl = torch.tensor(rng.normal(0, 1, (Mo, N))).float()
     lib = tnf._lib.lib
-    # one shared row at num_units = 64: the two-pass MFMA backward (coupling_wide_bwd.hip); per-context rows and MAF: the
+    # one shared row: the two-pass MFMA backward (coupling_wide_bwd.hip, RealNVP and MAF); per-context rows: the
     # shape-generic kernels -- both without atomics
-    fam = (tnf._lib.DIAG_BWD_WIDE if Mp == 1 else tnf._lib.DIAG_BWD_GENERIC) if kind == "coupling" else tnf._lib.DIAG_MAF_BWD_GENERIC
+    if kind == "coupling":
+        fam = tnf._lib.DIAG_BWD_WIDE if Mp == 1 else tnf._lib.DIAG_BWD_GENERIC
+    else:
+        fam = tnf._lib.DIAG_MAF_BWD_MFMA if Mp == 1 else tnf._lib.DIAG_MAF_BWD_GENERIC
     before = lib.tnf_diag_launch_count(fam)
     grads = []
     for _ in range(3):
@@ -854,3 +857,52 @@ def test_wide_shape_backward_mfma(tnf, oracle, D, L, U, upper, inverse, M, N):
         ((zo * wz).sum() + (ld * wl).sum()).backward()
         grad_err("wide MFMA backward vs the oracle: d params", res[0][0], pr.grad, 1.1e-6)  # 4 x 2.6e-7 / 6.3e-7 measured
         grad_err("wide MFMA backward vs the oracle: d z", res[0][1], zr.grad, 2.6e-6)
+
+
+@pytest.mark.parametrize("D,L,U,M,N", [
+    (64, 2, 64, 1, 1000), (48, 2, 64, 3, 333), (36, 1, 33, 1, 70), (64, 3, 32, 2, 50), (40, 2, 20, 1, 17),
+    (64, 2, 64, 1, (1 << 18) + 77),
+])
+def test_maf_wide_backward_mfma(tnf, oracle, D, L, U, M, N):
+    """Round 3: MAF beyond the one-kernel matrix-pipe backward (D > 32, up to 64; one shared parameter row) through the
+    two-pass fp32-MFMA backward (coupling_wide_bwd.hip: maf_wide_bwd_kernel + wide_gw_kernel with the masks applied on the
+    way out), against torch autograd over the oracle and against the shape-generic kernel it replaces; padded feature / unit
+    tiles, several sample batches of one row, a batch across the 2^18-sample record chunk; masked weights get exactly zero."""
+    rng = np.random.RandomState(D + U + N)
+    np.random.seed(D + L)
+    layer = tnf.MAF(D, L, U)
+    Ms = [Mk[0].numpy() for Mk in layer.Ms]
+    p0 = torch.tensor(rng.normal(0, 0.05, (1, layer.count_num_params()))).float()
+    z0 = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+    wz = torch.tensor(rng.normal(0, 1, (M, N, D))).float()
+    wl = torch.tensor(rng.normal(0, 1, (M, N))).float()
+    lib = tnf._lib.lib
+    fams = (tnf._lib.DIAG_MAF_BWD_MFMA, tnf._lib.DIAG_MAF_BWD_GENERIC)
+    res = []
+    for generic in (0, 1):
+        before = [lib.tnf_diag_launch_count(f) for f in fams]
+        lib.tnf_set_option(tnf._lib.OPT_FORCE_GENERIC, generic)
+        try:
+            p, z = p0.cuda().requires_grad_(), z0.cuda().requires_grad_()
+            zo, ld = layer.inverse_and_log_det(z, p)
+            ((zo * wz.cuda()).sum() + (ld * wl.cuda()).sum()).backward()
+            res.append((p.grad.cpu(), z.grad.cpu()))
+        finally:
+            lib.tnf_set_option(tnf._lib.OPT_FORCE_GENERIC, 0)
+        ran = [lib.tnf_diag_launch_count(f) - b for f, b in zip(fams, before)]
+        assert ran[generic] == 1 and ran[1 - generic] == 0, (generic, ran)
+    # measured 5.5e-6 / 7.6e-7 (bars 4 x).  The 5.5e-6 is the L = 3 case: with these 0.05-scale weights the third hidden
+    # layer's tanh outputs are ~0.01, and the matrix-pipe kernels carry h as 1 - 2 r with r = sigmoid near 0.5, i.e. with an
+    # ABSOLUTE quantisation of 1.2e-7 -- 1e-5 of such an h, hence of the output layer's weight gradient (h x delta); blocks
+    # fed by O(1) activations sit at 2e-7 .. 3e-7 like the generic kernel (scratch/mafwide_dbg.py prints the per-layer split)
+    grad_err("MAF wide MFMA backward vs the generic kernel: d params", res[0][0], res[1][0], 2.2e-5)
+    grad_err("MAF wide MFMA backward vs the generic kernel: d z", res[0][1], res[1][1], 3e-6)
+    mflat = torch.cat([torch.tensor(np.concatenate([Mk.reshape(-1), Mk.reshape(-1)])) for Mk in Ms])
+    assert mflat.numel() == res[0][0].numel()
+    assert torch.all(res[0][0][0][mflat == 0] == 0)
+    if N <= 1000:
+        pr, zr = p0.clone().requires_grad_(), z0.clone().requires_grad_()
+        zo, ld = oracle.maf(zr, pr, D, L, U, Ms, True)
+        ((zo * wz).sum() + (ld * wl).sum()).backward()
+        grad_err("MAF wide MFMA backward vs the oracle: d params", res[0][0], pr.grad, 2.2e-5)  # 4 x 5.6e-6 / 6.4e-7 measured
+        grad_err("MAF wide MFMA backward vs the oracle: d z", res[0][1], zr.grad, 2.6e-6)

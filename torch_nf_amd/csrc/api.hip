@@ -569,6 +569,13 @@ static int maf_backward_impl(int32_t dtype, const void* z, const void* params, c
         return launch_maf_backward_mfma((const float*)z, (const float*)params, (const float*)masks, (const float*)g_z_out,
                                         (const float*)g_log_det, (float*)g_z, (float*)g_params, M, M_p, N, D, L, U,
                                         pstride, gpstride, as_stream(stream));
+    // D > 32 (the one-kernel matrix-pipe backward stops there) with one shared parameter row: the two-pass MFMA backward
+    if (dtype == TNF_F32 && !g_force_generic && M_p == 1 && ws && maf_wide_bwd_supported(D, L, U) && aligned16(z) &&
+        aligned16(g_z_out) && aligned16(g_z) && aligned16(ws) && ws_bytes >= maf_wide_bwd_workspace(M * N, D, L, U))
+        return launch_maf_backward_wide((const float*)z, (const float*)params, (const float*)masks, (const float*)g_z_out,
+                                        (const float*)g_log_det, (float*)g_z, (float*)g_params, M * N, D, L, U, gpstride, ws,
+                                        as_stream(stream));
+    if (ws_bytes == 0 && maf_backward_workspace(dtype, M, M_p, N, D, L, U) > 0) ws_bytes = -1;
     return launch_maf_backward(dtype, z, params, masks, g_z_out, g_log_det, g_z, g_params, M, M_p, N, D, L, U,
                                pstride, gpstride, as_stream(stream), ws, ws_bytes);
 }
@@ -585,7 +592,12 @@ int64_t tnf_maf_backward_workspace_bytes(int32_t dtype, int64_t M, int64_t M_p, 
         return fail(TNF_EINVAL, "tnf_maf_backward_workspace_bytes: dtype=%d M=%lld M_p=%lld N=%lld D=%d L=%d U=%d", dtype,
                     (long long)M, (long long)M_p, (long long)N, D, L, U);
     if (dtype == TNF_F32 && !g_force_generic && maf_bwd_mfma_supported(D, L, U)) return 0;  // the MFMA kernel takes none
-    return maf_backward_workspace(dtype, M, M_p, N, D, L, U);
+    const int64_t gen = maf_backward_workspace(dtype, M, M_p, N, D, L, U);
+    if (dtype == TNF_F32 && !g_force_generic && M_p == 1 && maf_wide_bwd_supported(D, L, U)) {
+        const int64_t wide = maf_wide_bwd_workspace(M * N, D, L, U);
+        return wide > gen ? wide : gen;
+    }
+    return gen;
 }
 
 int tnf_maf_backward_ws(int32_t dtype, const void* z, const void* params, const void* masks, const void* g_z_out,

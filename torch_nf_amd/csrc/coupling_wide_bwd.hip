@@ -23,6 +23,7 @@
 //
 // Records cost 4 (3 HT + 4 L UT) KB per 16 samples (2.4 KB per sample at D = 64, U = 64, L = 2): written once, read once,
 // chunked to 2^18 samples so that the workspace stays below 1 GB whatever N is.
+#include "maf_tile.h"
 #include "wide_tile.h"
 
 namespace tnf {
@@ -333,8 +334,9 @@ struct WideGwArgs {
     const float* rec;
     float* partials;  // [G][P]
     int64_t ntiles;   // sample tiles of the chunk
-    int H, U, L, P, G;
+    int H, U, L, P, G;  // H: width of the first layer's input = of the last layer's output (D / 2; D for MAF)
     WideRec rc;
+    const float* masks;  // MAF: the layers' binary masks (shared by both nets), gradients are mask * sum; no biases
 };
 
 template <int TB>
@@ -376,9 +378,14 @@ wide_gw_kernel(WideGwArgs a) {
     const int a_blk0 = last ? a.rc.dout(net, 0) : a.rc.da(layer, net, 0);
     const int b_blk0 = first ? a.rc.x(0) : a.rc.act(layer - 1, net, 0);
     const int din = first ? H : U, dout = last ? H : U;
-    // parameter offsets (bijectors.py:222-235): per MLP layer [W_t | W_s | b_t | b_s], W[in][out]
-    int64_t off = 0;
-    for (int l = 0; l < layer; ++l) off += 2 * ((int64_t)(l == 0 ? H : U) * U + U);
+    // parameter offsets: RealNVP (bijectors.py:222-235) per MLP layer [W_t | W_s | b_t | b_s], W[in][out];
+    // MAF (bijectors.py:698-740) per layer [W_mu | W_alpha], no biases, one mask per layer
+    const bool maf = a.masks != nullptr;
+    int64_t off = 0, moff = 0;
+    for (int l = 0; l < layer; ++l) {
+        off += 2 * ((int64_t)(l == 0 ? H : U) * U + (maf ? 0 : U));
+        moff += (int64_t)(l == 0 ? H : U) * U;
+    }
     const int64_t wbase = off + (int64_t)net * din * dout, bbase = off + 2 * (int64_t)din * dout + (int64_t)net * dout;
     const int64_t per = (a.ntiles + a.G - 1) / a.G;
     const int64_t t0 = slice * per, t1 = (t0 + per) < a.ntiles ? (t0 + per) : a.ntiles;
@@ -407,9 +414,11 @@ wide_gw_kernel(WideGwArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int o = 16 * ta + 4 * q + j;
-            if (k < din && o < dout) part[wbase + (int64_t)k * dout + o] = acc[tb][j];
+            if (k < din && o < dout)
+                part[wbase + (int64_t)k * dout + o] = maf ? acc[tb][j] * a.masks[moff + (int64_t)k * dout + o] : acc[tb][j];
         }
     }
+    if (maf) return;
     // bias: row sum of the delta block -- this lane holds samples 4q .. 4q+3 of row c
     bsum += __shfl_xor(bsum, 16);
     bsum += __shfl_xor(bsum, 32);
@@ -495,7 +504,7 @@ int launch_coupling_backward_wide(const float* z, const float* params, const flo
     for (int64_t ci = 0; ci < nchunks; ++ci) {
         WideBwdArgs a{z, params, g_zout, g_ld, g_z, rec, partials + ci * kWideBwdSlices * P, N, ci * kWideBwdChunk,
                       (ci + 1) * kWideBwdChunk < N ? (ci + 1) * kWideBwdChunk : N, D, U, upper, inverse};
-        WideGwArgs g{rec, a.partials, (a.n1 - a.n0 + 15) / 16, D / 2, U, L, (int)P, kWideBwdSlices, rc};
+        WideGwArgs g{rec, a.partials, (a.n1 - a.n0 + 15) / 16, D / 2, U, L, (int)P, kWideBwdSlices, rc, nullptr};
         int rcode;
         switch (wl.HT) {
             case 1: rcode = launch_wide_bwd_u<1>(a, g, wl, bl, smem, st); break;
@@ -506,6 +515,345 @@ int launch_coupling_backward_wide(const float* z, const float* params, const flo
         if (rcode != TNF_OK) return rcode;
     }
     const int rcode = check_launch("coupling_wide_bwd");
+    if (rcode) return rcode;
+    return launch_backward_reduce(TNF_F32, partials, g_params, 1, (int)(nchunks * kWideBwdSlices), P, gpstride, st);
+}
+
+// ---------------------------------------------------------------------------
+// MAF (bijectors.py:597-806), inverse direction -- what log_prob training differentiates -- for the shapes the one-kernel
+// matrix-pipe backward (maf_bwd_mfma.hip, D <= 32) does not reach: D up to 64 (D % 4 == 0), num_units up to 64.  Same two
+// passes: pass 1 below, pass 2 = wide_gw_kernel with the masks applied on the way out (and no biases).  The forward
+// image (masked, folded: maf_tile.h) sits in LDS; the transposed masked raw weights of the way back would not fit beside it
+// at D = U = 64 (2 x 96 KB), so they are an image in global memory (maf_bwd_timage_kernel, 96 KB, L2-resident) read 16 bytes
+// per lane and group.
+//   out = (z - mu) e^-alpha, ld = sum alpha:   dz = g e^-alpha + (nets' input gradient),  dmu = -g e^-alpha,
+//   dalpha = -g out + g_ld
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+maf_bwd_timage_kernel(const float* __restrict__ p, const float* __restrict__ mk, float* __restrict__ timg, WideBwdLayout bl,
+                      int D, int U) {
+    // group = blockIdx.x, in the order of WideBwdLayout (HT = DT): [W2 (net, ui, mo) | Wh (l, net, ui, uo) | W0 (net, m, ut)]
+    const int g = blockIdx.x, lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    const int n2 = bl.nB2(), nh = bl.nBh();
+    f4 v;
+    if (g < n2) {  // output layer U -> D
+        const int net = g / (bl.UT * bl.HT), ui = (g / bl.HT) % bl.UT, mo = g % bl.HT;
+        const float* w = p + 2 * (int64_t)D * U + (int64_t)(bl.L - 1) * 2 * U * U + (int64_t)net * U * D;
+        const float* m = mk + (int64_t)D * U + (int64_t)(bl.L - 1) * U * U;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 16 * ui + r, o = 16 * mo + 4 * q + j;
+            const bool ok = k < U && o < D;
+            v[j] = ld_sel(w, k * D + o, ok) * ld_sel(m, k * D + o, ok);
+        }
+    } else if (g < n2 + (bl.L - 1) * nh) {  // hidden layer l + 1: U -> U
+        const int gg = g - n2, l = gg / nh, rr = gg % nh;
+        const int net = rr / (bl.UT * bl.UT), ui = (rr / bl.UT) % bl.UT, uo = rr % bl.UT;
+        const float* w = p + 2 * (int64_t)D * U + (int64_t)l * 2 * U * U + (int64_t)net * U * U;
+        const float* m = mk + (int64_t)D * U + (int64_t)l * U * U;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ki = 16 * ui + r, ko = 16 * uo + 4 * q + j;
+            const bool ok = ki < U && ko < U;
+            v[j] = ld_sel(w, ki * U + ko, ok) * ld_sel(m, ki * U + ko, ok);
+        }
+    } else {  // layer 0: D -> U
+        const int gg = g - n2 - (bl.L - 1) * nh;
+        const int net = gg / (bl.HT * bl.UT), mm = (gg / bl.UT) % bl.HT, ut = gg % bl.UT;
+        const float* w = p + (int64_t)net * D * U;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 16 * mm + r, u = 16 * ut + 4 * q + j;
+            const bool ok = f < D && u < U;
+            v[j] = ld_sel(w, f * U + u, ok) * ld_sel(mk, f * U + u, ok);
+        }
+    }
+    *reinterpret_cast<f4*>(timg + (int64_t)g * 256 + lane * 4) = v;
+}
+
+struct MafWideBwdArgs {
+    const float* z;
+    const float* params;
+    const float* masks;
+    const float* timg;    // transposed masked raw image (global)
+    const float* g_zout;
+    const float* g_ld;
+    float* g_z;
+    float* rec;
+    int64_t n0, n1;
+    int D, U;
+};
+
+template <int DT, int UT, int L>
+__global__ void __launch_bounds__(256)
+maf_wide_bwd_kernel(MafWideBwdArgs a, MafLayout wl, WideBwdLayout bl, WideRec rc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int D = a.D, U = a.U;
+    float* img = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, q = lane >> 4;
+    build_maf_image(img, a.params, a.masks, wl, D, U, lane, wave, 4, 0);
+    __syncthreads();
+    const float* wsrc = img + lane * 4;
+    const float* bsrc = img + wl.NWG() * 256 + q * 4;
+    const float* tsrc = a.timg + lane * 4;
+    auto wgrp = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(wsrc + g * 256); };
+    auto bgrp = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(bsrc + g * 16); };
+    auto tgrp = [&](int g) -> f4 { return *reinterpret_cast<const f4*>(tsrc + (int64_t)g * 256); };
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    bool fok[DT];
+#pragma unroll
+    for (int mm = 0; mm < DT; ++mm) fok[mm] = 16 * mm + 4 * q < D;
+
+    const int64_t tile0 = a.n0 >> 4, ntiles = (a.n1 - a.n0 + 15) >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t row = (tile0 + t) * 16 + s;
+        const bool row_ok = row < a.n1;
+        const int64_t rowc = row_ok ? row : a.n1 - 1;
+        float* rec = a.rec + t * (int64_t)rc.blocks() * 256;
+        const float* zr = a.z + rowc * D + 4 * q;
+        const float* gr = a.g_zout + rowc * D + 4 * q;
+        f4 x[DT], g[DT];
+#pragma unroll
+        for (int mm = 0; mm < DT; ++mm) {
+            x[mm] = fok[mm] ? *reinterpret_cast<const f4*>(zr + 16 * mm) : zero;
+            g[mm] = (fok[mm] && row_ok) ? *reinterpret_cast<const f4*>(gr + 16 * mm) : zero;
+            store_block(rec + rc.x(mm) * 256, x[mm], s, q);
+        }
+        const float gl = row_ok ? a.g_ld[rowc] : 0.f;
+        asm volatile("" ::: "memory");
+
+        f4 r[L][2][UT];
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            f4 at = zero, as = zero;  // MAF has no biases: layer 0 starts from zero
+#pragma unroll
+            for (int mm = 0; mm < DT; ++mm) {
+                const f4 wt = wgrp(wl.g_w0(0, ut, mm)), ws = wgrp(wl.g_w0(1, ut, mm));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    at = mfma4(wt[j], x[mm][j], at);
+                    as = mfma4(ws[j], x[mm][j], as);
+                }
+            }
+            r[0][0][ut] = sig2_4(at);
+            r[0][1][ut] = sig2_4(as);
+        }
+#pragma unroll
+        for (int l = 0; l < L - 1; ++l)
+#pragma unroll
+            for (int uo = 0; uo < UT; ++uo) {
+                f4 at = bgrp(wl.b_bh(l, 0, uo)), as = bgrp(wl.b_bh(l, 1, uo));
+#pragma unroll
+                for (int ui = 0; ui < UT; ++ui) {
+                    const f4 wt = wgrp(wl.g_wh(l, 0, uo, ui)), ws = wgrp(wl.g_wh(l, 1, uo, ui));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        at = mfma4(wt[j], r[l][0][ui][j], at);
+                        as = mfma4(ws[j], r[l][1][ui][j], as);
+                    }
+                }
+                r[l + 1][0][uo] = sig2_4(at);
+                r[l + 1][1][uo] = sig2_4(as);
+            }
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int net = 0; net < 2; ++net)
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut) {
+                    f4 h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = __builtin_fmaf(-2.f, r[l][net][ut][j], 1.f);
+                    store_block(rec + rc.act(l, net, ut) * 256, h, s, q);
+                }
+        f4 dout[2][DT], dx[DT];
+#pragma unroll
+        for (int mo = 0; mo < DT; ++mo) {
+            f4 mu = bgrp(wl.b_b2(0, mo)), al2 = bgrp(wl.b_b2(1, mo));
+#pragma unroll
+            for (int ui = 0; ui < UT; ++ui) {
+                const f4 wt = wgrp(wl.g_w2(0, mo, ui)), ws = wgrp(wl.g_w2(1, mo, ui));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mu = mfma4(wt[j], r[L - 1][0][ui][j], mu);
+                    al2 = mfma4(ws[j], r[L - 1][1][ui][j], al2);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float em = __builtin_amdgcn_exp2f(-al2[j]);
+                const float out = (x[mo][j] - mu[j]) * em;
+                const float dz = g[mo][j] * em;
+                const bool real = 16 * mo + 4 * q + j < D;
+                dx[mo][j] = dz;                                               // direct path; the nets' share is added below
+                dout[0][mo][j] = real ? -dz : 0.f;                            // d mu
+                dout[1][mo][j] = real ? __builtin_fmaf(-g[mo][j], out, gl) : 0.f;  // d alpha
+            }
+            store_block(rec + rc.dout(0, mo) * 256, dout[0][mo], s, q);
+            store_block(rec + rc.dout(1, mo) * 256, dout[1][mo], s, q);
+        }
+        f4 dh[2][UT];
+#pragma unroll
+        for (int net = 0; net < 2; ++net)
+#pragma unroll
+            for (int ui = 0; ui < UT; ++ui) {
+                f4 acc = zero;
+#pragma unroll
+                for (int mo = 0; mo < DT; ++mo) {
+                    const f4 wb = tgrp(bl.g_b2(net, ui, mo));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = mfma4(wb[j], dout[net][mo][j], acc);
+                }
+                dh[net][ui] = acc;
+            }
+#pragma unroll
+        for (int l = L - 2; l >= 0; --l)
+#pragma unroll
+            for (int net = 0; net < 2; ++net) {
+                f4 da[UT];
+#pragma unroll
+                for (int uo = 0; uo < UT; ++uo) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float rr = r[l + 1][net][uo][j];
+                        da[uo][j] = dh[net][uo][j] * (4.f * rr * (1.f - rr));
+                    }
+                    store_block(rec + rc.da(l + 1, net, uo) * 256, da[uo], s, q);
+                }
+#pragma unroll
+                for (int ui = 0; ui < UT; ++ui) {
+                    f4 acc = zero;
+#pragma unroll
+                    for (int uo = 0; uo < UT; ++uo) {
+                        const f4 wb = tgrp(bl.g_bh(l, net, ui, uo));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = mfma4(wb[j], da[uo][j], acc);
+                    }
+                    dh[net][ui] = acc;
+                }
+            }
+#pragma unroll
+        for (int net = 0; net < 2; ++net) {
+            f4 da[UT];
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float rr = r[0][net][ut][j];
+                    da[ut][j] = dh[net][ut][j] * (4.f * rr * (1.f - rr));
+                }
+                store_block(rec + rc.da(0, net, ut) * 256, da[ut], s, q);
+            }
+#pragma unroll
+            for (int mm = 0; mm < DT; ++mm)
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut) {
+                    const f4 wb = tgrp(bl.g_b0(net, mm, ut));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dx[mm] = mfma4(wb[j], da[ut][j], dx[mm]);
+                }
+        }
+        if (row_ok) {
+#pragma unroll
+            for (int mm = 0; mm < DT; ++mm)
+                if (fok[mm]) *reinterpret_cast<f4*>(a.g_z + row * D + 4 * q + 16 * mm) = dx[mm];
+        }
+    }
+}
+
+static MafLayout maf_wide_layout(int D, int L, int U) {
+    MafLayout wl;
+    wl.UT = (U + 15) / 16;
+    wl.DT = (D + 15) / 16;
+    wl.L = L;
+    return wl;
+}
+
+bool maf_wide_bwd_supported(int D, int L, int U) {
+    if (D < 4 || D > 64 || (D % 4) != 0 || U < 1 || U > 64 || L < 1) return false;
+    const MafLayout wl = maf_wide_layout(D, L, U);
+    if (L > wide_bwd_lmax(wl.UT)) return false;
+    return (size_t)wl.floats() * sizeof(float) <= 156 * 1024;
+}
+
+static int64_t maf_num_params_(int D, int L, int U) { return 2 * (2 * (int64_t)D * U + (int64_t)(L - 1) * U * U); }
+
+// workspace: [transposed image | records of one chunk | partial rows]
+int64_t maf_wide_bwd_workspace(int64_t N, int D, int L, int U) {
+    const MafLayout wl = maf_wide_layout(D, L, U);
+    const WideBwdLayout bl{wl.UT, wl.DT, L};
+    const WideRec rc{wl.UT, wl.DT, L};
+    const int64_t chunk = N < kWideBwdChunk ? N : kWideBwdChunk;
+    return (int64_t)bl.floats() * 4 + ((chunk + 15) / 16) * rc.blocks() * 1024 +
+           wide_bwd_chunks(N) * kWideBwdSlices * maf_num_params_(D, L, U) * 4;
+}
+
+template <int DT, int UT, int L>
+static int launch_maf_wide_t(const MafWideBwdArgs& a, const WideGwArgs& g, const MafLayout& wl, const WideBwdLayout& bl,
+                             size_t smem, hipStream_t st) {
+    auto k = maf_wide_bwd_kernel<DT, UT, L>;
+    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return fail(TNF_ELAUNCH, "maf_wide_bwd: cannot reserve %zu B of LDS", smem);
+    const int64_t ntiles = (a.n1 - a.n0 + 15) / 16;
+    int64_t bx = (ntiles + 3) / 4;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(k, dim3((unsigned)bx), dim3(256), smem, st, a, wl, bl, g.rc);
+    hipLaunchKernelGGL((wide_gw_kernel<DT, UT>), dim3((unsigned)(2 * (L + 1) * g.G)), dim3(256), 0, st, g);
+    return TNF_OK;
+}
+template <int DT, int UT>
+static int launch_maf_wide_l(const MafWideBwdArgs& a, const WideGwArgs& g, const MafLayout& wl, const WideBwdLayout& bl,
+                             size_t smem, hipStream_t st) {
+    if (wl.L == 1) return launch_maf_wide_t<DT, UT, 1>(a, g, wl, bl, smem, st);
+    if (wl.L == 2) return launch_maf_wide_t<DT, UT, 2>(a, g, wl, bl, smem, st);
+    if constexpr (UT <= 2) return launch_maf_wide_t<DT, UT, 3>(a, g, wl, bl, smem, st);
+    return fail(TNF_EUNSUPPORTED, "maf_wide_bwd: num_layers=%d with %d unit tiles", wl.L, UT);
+}
+template <int DT>
+static int launch_maf_wide_u(const MafWideBwdArgs& a, const WideGwArgs& g, const MafLayout& wl, const WideBwdLayout& bl,
+                             size_t smem, hipStream_t st) {
+    switch (wl.UT) {
+        case 1: return launch_maf_wide_l<DT, 1>(a, g, wl, bl, smem, st);
+        case 2: return launch_maf_wide_l<DT, 2>(a, g, wl, bl, smem, st);
+        case 3: return launch_maf_wide_l<DT, 3>(a, g, wl, bl, smem, st);
+        default: return launch_maf_wide_l<DT, 4>(a, g, wl, bl, smem, st);
+    }
+}
+
+int launch_maf_backward_wide(const float* z, const float* params, const float* masks, const float* g_zout, const float* g_ld,
+                             float* g_z, float* g_params, int64_t N, int D, int L, int U, int64_t gpstride, void* ws,
+                             hipStream_t st) {
+    if (!maf_wide_bwd_supported(D, L, U)) return fail(TNF_EUNSUPPORTED, "maf_wide_bwd: D=%d L=%d U=%d", D, L, U);
+    if (N <= 0) return TNF_OK;
+    diag_count(TNF_DIAG_MAF_BWD_MFMA);
+    const MafLayout wl = maf_wide_layout(D, L, U);
+    const WideBwdLayout bl{wl.UT, wl.DT, L};
+    const WideRec rc{wl.UT, wl.DT, L};
+    const size_t smem = (size_t)wl.floats() * sizeof(float);
+    const int64_t P = maf_num_params_(D, L, U);
+    const int64_t chunk = N < kWideBwdChunk ? N : kWideBwdChunk;
+    char* wsb = reinterpret_cast<char*>(ws);
+    float* timg = reinterpret_cast<float*>(wsb);
+    float* rec = reinterpret_cast<float*>(wsb + (int64_t)bl.floats() * 4);
+    float* partials = reinterpret_cast<float*>(wsb + (int64_t)bl.floats() * 4 + ((chunk + 15) / 16) * rc.blocks() * 1024);
+    hipLaunchKernelGGL(maf_bwd_timage_kernel, dim3((unsigned)(bl.floats() / 256)), dim3(64), 0, st, params, masks, timg, bl, D, U);
+    const int64_t nchunks = wide_bwd_chunks(N);
+    for (int64_t ci = 0; ci < nchunks; ++ci) {
+        float* part = partials + ci * kWideBwdSlices * P;
+        MafWideBwdArgs a{z, params, masks, timg, g_zout, g_ld, g_z, rec, ci * kWideBwdChunk,
+                         (ci + 1) * kWideBwdChunk < N ? (ci + 1) * kWideBwdChunk : N, D, U};
+        WideGwArgs g{rec, part, (a.n1 - a.n0 + 15) / 16, D, U, L, (int)P, kWideBwdSlices, rc, masks};
+        int rcode;
+        switch (wl.DT) {
+            case 1: rcode = launch_maf_wide_u<1>(a, g, wl, bl, smem, st); break;
+            case 2: rcode = launch_maf_wide_u<2>(a, g, wl, bl, smem, st); break;
+            case 3: rcode = launch_maf_wide_u<3>(a, g, wl, bl, smem, st); break;
+            default: rcode = launch_maf_wide_u<4>(a, g, wl, bl, smem, st); break;
+        }
+        if (rcode != TNF_OK) return rcode;
+    }
+    const int rcode = check_launch("maf_wide_bwd");
     if (rcode) return rcode;
     return launch_backward_reduce(TNF_F32, partials, g_params, 1, (int)(nchunks * kWideBwdSlices), P, gpstride, st);
 }

@@ -116,6 +116,11 @@ int launch_coupling_wide(const MfmaLayerArgs& a, hipStream_t st);
 // MFMA backward of the wide shapes (coupling_wide_bwd.hip): one shared parameter row, N = all samples of the call
 bool wide_bwd_supported(int D, int L, int U);
 int64_t wide_bwd_workspace(int64_t N, int D, int L, int U);
+bool maf_wide_bwd_supported(int D, int L, int U);
+int64_t maf_wide_bwd_workspace(int64_t N, int D, int L, int U);
+int launch_maf_backward_wide(const float* z, const float* params, const float* masks, const float* g_zout, const float* g_ld,
+                             float* g_z, float* g_params, int64_t N, int D, int L, int U, int64_t gpstride, void* ws,
+                             hipStream_t st);
 int launch_coupling_backward_wide(const float* z, const float* params, const float* g_zout, const float* g_ld, float* g_z,
                                   float* g_params, int64_t N, int D, int L, int U, int upper, int inverse,
                                   int64_t gpstride, void* ws, hipStream_t st);
