@@ -237,3 +237,35 @@ def test_cond_flow_sampling_direction(tnf, oracle, D, S, L, U, Dx, hidden, M):
         lp_s = cde.log_prob(z_s, xd)
     torch.testing.assert_close(lp_s.double(), lq_s, rtol=1e-5, atol=2e-4)
     assert not cde._fused_sampling_ok(xd)  # grad mode, parameters require grad
+
+
+def test_cond_flow_trunk_split_k_weight_gradients(tnf):
+    """From 32,768 contexts on, the hidden Linears of param_net get their weight gradients as batched products over row
+    blocks (`_SplitKLinear`: the stock g^T x is one K = M GEMM on a handful of workgroups).  Same gradients as the stock
+    modules (fuse off -> materialised path through nn.Linear's own backward), ragged row count, dropout-free."""
+    D, S, L, U, Dx, hidden, M = 32, 1, 2, 15, 6, [64, 32], 32768 + 77
+    nf, cde = _make(tnf, D, S, L, U, Dx, hidden, 5)
+    x = torch.randn(M, Dx, device="cuda")
+    z = torch.randn(M, 1, D, device="cuda")
+    grads = []
+    for fuse in (True, False):
+        cde.fuse_conditioner = fuse
+        cde.zero_grad()
+        (-cde.log_prob(z, x).mean()).backward()
+        grads.append([p.grad.clone() for p in cde.param_net.parameters()])
+    cde.fuse_conditioner = True
+    for a, b in zip(*grads):
+        scale = float(b.abs().max().clamp_min(1e-30))
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (float((a - b).abs().max()), scale)
+    # and the helper on its own against the stock module, exactly the same rows
+    lin = torch.nn.Linear(48, 64).cuda()
+    inp = torch.randn(40000 + 3, 48, device="cuda", requires_grad=True)
+    gout = torch.randn(40000 + 3, 64, device="cuda")
+    from torch_nf_amd.conditional_density_estimator import _SplitKLinear
+    y0 = lin(inp)
+    g0 = torch.autograd.grad(y0, [inp, lin.weight, lin.bias], gout)
+    y1 = _SplitKLinear.apply(inp, lin.weight, lin.bias)
+    g1 = torch.autograd.grad(y1, [inp, lin.weight, lin.bias], gout)
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+    for a, b in zip(g1, g0):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-3)

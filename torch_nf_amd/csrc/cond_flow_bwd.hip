@@ -16,6 +16,8 @@
 //    contexts; its waves share the staged x / delta / h chunk and each owns a few input units k), with
 //    no atomics beyond the final few-way merge of the context slices.
 // MFMA work: kernel 1 = 2x the forward, kernel 2 = 1x.
+#include <type_traits>
+
 #include "cond_tile.h"
 
 namespace tnf {
@@ -631,9 +633,9 @@ struct GwArgs {
     int jobs, spp;  // jobs per context slice; 128-context (64 at H = 128) steps per slice
 };
 
-// A job = up to four SEGMENTS that share the staged h operands: a segment is one (MLP layer, net, 16-output
+// A job = up to two SEGMENTS that share the staged h operands: a segment is one (MLP layer, net, 16-output
 // tile) -- d_in weight rows + one bias row, one delta tile -- or one Affine 16-feature tile (bias row only).
-// The t and s nets of the hidden / output layers are merged into one job (2 x 17 items), the four alpha or
+// The t and s nets of the hidden / output layers are merged into one job (2 x 17 items), pairs of alpha or
 // shift tiles of an Affine too; the 33-item layer-0 nets stay separate.  All segments of a job have the
 // same d_in.
 struct GwSeg {
@@ -644,35 +646,36 @@ struct GwSeg {
     int wk, count;
 };
 struct GwJob {
-    GwSeg seg[4];
+    GwSeg seg[2];
     int64_t xs, dstr;
     int nseg, d_in;
 };
 
-__device__ inline int gw_jobs_per_stage(const CondCfg& c) { return 2 * (2 + (c.L - 1) + c.HT) + 2; }
+__host__ __device__ inline int gw_jobs_per_stage(const CondCfg& c) { return 2 * (2 + (c.L - 1) + c.HT) + 2 * c.HT; }
 
 __device__ inline GwJob gw_job(const GwArgs& a, int job) {
     const CondCfg& c = a.cfg;
     const int Hd = c.D / 2, U = c.U, L = c.L;
-    const int JC = 2 + (L - 1) + c.HT, JS = 2 * JC + 2;
+    const int JC = 2 + (L - 1) + c.HT, JS = 2 * JC + 2 * c.HT;
     const int CR = 3 * Hd + 32 * L, DR = 2 * Hd + 32 * L;
     const int si = job / JS, stage = c.S - 1 - si;
     int r = job % JS;
     GwJob j;
     const int64_t so = (int64_t)stage * c.fl.stage;
-    if (r >= 2 * JC) {  // Affine: gP = g_alpha (job 0) / g_shift (job 1) themselves, one segment per 16 features
-        const int which = r - 2 * JC;
-        j.nseg = c.DT;
+    if (r >= 2 * JC) {  // Affine: gP = g_alpha / g_shift themselves, one segment per 16 features, two per job
+        const int which = (r - 2 * JC) / c.HT, pair = (r - 2 * JC) % c.HT;
+        j.nseg = 2;
         j.d_in = 0;
         j.xs = 0;
         j.dstr = 2 * c.D;
-        for (int t = 0; t < c.DT; ++t) {
+        for (int t = 0; t < 2; ++t) {
             GwSeg& g = j.seg[t];
+            const int ft = 2 * pair + t;
             g.x = nullptr;
-            g.d = a.d_aff + (int64_t)si * a.M * 2 * c.D + which * c.D + 16 * t;
+            g.d = a.d_aff + (int64_t)si * a.M * 2 * c.D + which * c.D + 16 * ft;
             g.wbase = 0;
             g.wk = 0;
-            g.bbase = so + c.fl.p_up + c.fl.p_low + which * c.D + 16 * t;
+            g.bbase = so + c.fl.p_up + c.fl.p_low + which * c.D + 16 * ft;
             g.count = 16;
         }
         return j;
@@ -755,21 +758,54 @@ cond_hsplit_kernel(const float* __restrict__ h, int64_t ldh, int64_t M, u4* __re
     }
 }
 
+#ifndef TNF_GW_NW
+#define TNF_GW_NW 8
+#endif
+#ifndef TNF_GW_CH
+#define TNF_GW_CH 128
+#endif
+constexpr int kGwNW = TNF_GW_NW;
+template <int KS>
+__host__ __device__ constexpr int gw_ch() { return KS == 4 ? 64 : TNF_GW_CH; }
+
+// a 16-byte LDS read the compiler does not see as one (no s_waitcnt of its own: the caller waits lgkmcnt(0) before use)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ h8 lds_read16_blind(unsigned base) {
+    h8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF));
+    return v;
+}
+
 template <int DT, int KS, int NW>
-__global__ void __launch_bounds__(64 * NW)
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 cond_gw_kernel(GwArgs a) {
     constexpr int JT = 2 * KS, NT = 64 * NW;
     constexpr int XR = 32;                        // staged x rows: one 32-wide layer-0 input or 2 x 16 hidden units
     constexpr int IPW = (XR + 2 + NW - 1) / NW;   // items (weight rows + bias rows of all segments) per wave
-    constexpr int CH = KS == 4 ? 64 : 128;        // contexts staged per step
+    constexpr int CH = gw_ch<KS>();               // contexts staged per step
     constexpr int CS = CH + 4;                    // padded row stride of the transposed staging buffers
     constexpr int NX = (CH * (XR / 4) + NT - 1) / NT, ND = (CH * 16 + NT - 1) / NT;
     constexpr int HB_U4 = (CH / 32) * JT * 2 * 64;  // one step's h operands (32 KB at H = 64)
-    __shared__ __attribute__((aligned(16))) float xT[(XR + 1) * CS];   // row XR: ones (the bias items)
-    __shared__ __attribute__((aligned(16))) float dT[4 * 16 * CS];     // one delta tile per segment
+    // two staging buffers each: a wave writes the next step's rows right behind its own MFMAs of this step, and ONE
+    // barrier per step publishes them (with two barriers around a single buffer every wave waited for the slowest twice)
+    constexpr int XTF = (XR + 1) * CS, DTF = 2 * 16 * CS;
+    __shared__ __attribute__((aligned(16))) float xT2[2 * XTF];   // row XR: ones (the bias items)
+    __shared__ __attribute__((aligned(16))) float dT2[2 * DTF];   // one delta tile per segment
     // h as ready MFMA B operands [sub-step][jt][hi/lo][lane], copied from the pre-split image by LDS-DMA
     // (contiguous), two slots
-    __shared__ __attribute__((aligned(16))) u4 hB[2 * HB_U4];
+    // two OBJECTS, and the step loop below unrolled by two so that each access names one of them at compile time: hipcc
+    // orders an LDS read behind every LDS-DMA copy in flight that it cannot prove disjoint (s_waitcnt vmcnt(0) in front of
+    // the first operand read -- the whole fetch latency exposed once per step when this was one array with a run-time slot)
+    __shared__ __attribute__((aligned(16))) u4 hB0[HB_U4];
+    __shared__ __attribute__((aligned(16))) u4 hB1[HB_U4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     // XCD-aware placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own
@@ -792,63 +828,85 @@ cond_gw_kernel(GwArgs a) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) acc[i][jt] = zero;
     }
-    for (int i = tid; i < CS; i += NT) xT[XR * CS + i] = 1.f;
+    for (int i = tid; i < CS; i += NT) xT2[XR * CS + i] = xT2[XTF + XR * CS + i] = 1.f;
 
     // register-staged prefetch of one step: x rows and delta rows of CH contexts (zero past M)
     f4 px[NX], pd[ND];
     const int64_t himg_u4 = ((a.M + 31) / 32) * JT * 2 * 64;
-    auto fetch_h = [&](int64_t step, int slot) {  // asynchronous: lands in hB[slot] before the barrier after next
+    auto fetch_h = [&](int64_t step, u4* hdst) {  // asynchronous: complete behind the issuing wave's vmcnt(0) + a barrier
         const int64_t base = step * HB_U4;
         for (int i = wave; i < HB_U4 / 64; i += NW) {
             int64_t g = base + i * 64 + lane;
             g = g < himg_u4 ? g : himg_u4 - 1;  // past the last group: never used (x and delta are zero there)
-            __builtin_amdgcn_global_load_lds(a.himg + g, (lds_void*)(hB + slot * HB_U4 + i * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(a.himg + g, (lds_void*)(hdst + i * 64), 16, 0, 0);
         }
     };
     const int xrow4 = job.nseg * xq;  // float4 per context over all segments
+    // which (context, segment, float4) of a step this thread stages: the same every step, so the divisions by the job's
+    // run-time extents are done once (they were half of the kernel's vector instructions when redone per step)
+    const float* xsrc[NX];
+    const float* dsrc[ND];
+    int xctx[NX], xdst[NX], xne[NX], dctx[ND], ddst[ND], dne[ND];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int idx = tid + i * NT;
+        const int ctx = xrow4 ? idx / xrow4 : 0, k4g = xrow4 ? idx - ctx * xrow4 : 0;
+        const int sg = xq ? k4g / xq : 0, k4 = xq ? k4g - sg * xq : 0;
+        const bool ok = xrow4 && ctx < CH;
+        xctx[i] = ok ? ctx : -1;
+        xsrc[i] = ok ? job.seg[sg].x + 4 * k4 : a.h;
+        xdst[i] = (sg * job.d_in + 4 * k4) * CS + ctx;
+        const int left = job.d_in - 4 * k4;
+        xne[i] = ok ? (left < 4 ? left : 4) : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int idx = tid + i * NT;
+        const int ctx = idx / (4 * job.nseg), rem = idx - ctx * 4 * job.nseg;
+        const int sg = rem >> 2, o4 = rem & 3;
+        const bool ok = ctx < CH;
+        dctx[i] = ok ? ctx : -1;
+        dsrc[i] = job.seg[sg].d + 4 * o4;
+        ddst[i] = (sg * 16 + 4 * o4) * CS + ctx;
+        const int left = job.seg[sg].count - 4 * o4;
+        dne[i] = left < 0 ? 0 : (left < 4 ? left : 4);
+    }
+    // The loaded registers are not touched before commit() (rows past M are clamped to row M - 1 here and zeroed there): any
+    // instruction on them in between would make the wave wait for the loads before its MFMAs instead of behind them.  The
+    // pointers come out of the job descriptor in LDS, so they are cast to the global address space by hand (generic `flat`
+    // loads would also count on lgkmcnt, against the LDS operand reads).
+    typedef const __attribute__((address_space(1))) f4* gf4p;
+    const int64_t mlast = a.M - 1;
     auto fetch = [&](int64_t mbase) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * NT;
-            const int ctx = xrow4 ? idx / xrow4 : 0, k4g = xrow4 ? idx - ctx * xrow4 : 0;
-            const int sg = xq ? k4g / xq : 0, k4 = xq ? k4g - sg * xq : 0;
-            const int64_t m = mbase + ctx;
-            const bool ok = xrow4 && ctx < CH && m < a.M;
-            const f4 v = *reinterpret_cast<const f4*>((ok ? job.seg[sg].x + m * job.xs + 4 * k4 : a.h));
-            px[i] = ok ? v : zero;
+            int64_t m = mbase + (xctx[i] >= 0 ? xctx[i] : 0);
+            m = m < a.M ? m : mlast;
+            px[i] = *(gf4p)(xsrc[i] + (xctx[i] >= 0 ? m * job.xs : 0));
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int idx = tid + i * NT;
-            const int ctx = idx / (4 * job.nseg), rem = idx - ctx * 4 * job.nseg;
-            const int sg = rem >> 2, o4 = rem & 3;
-            const int64_t m = mbase + ctx;
-            const bool ok = ctx < CH && m < a.M;
-            const f4 v = *reinterpret_cast<const f4*>(job.seg[sg].d + (ok ? m : 0) * job.dstr + 4 * o4);
-            pd[i] = ok ? v : zero;
+            int64_t m = mbase + (dctx[i] >= 0 ? dctx[i] : 0);
+            m = m < a.M ? m : mlast;
+            pd[i] = *(gf4p)(dsrc[i] + m * job.dstr);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf, int64_t mbase) {
+        float* xT = xT2 + buf * XTF;
+        float* dT = dT2 + buf * DTF;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * NT;
-            const int ctx = xrow4 ? idx / xrow4 : 0, k4g = xrow4 ? idx - ctx * xrow4 : 0;
-            const int sg = xq ? k4g / xq : 0, k4 = xq ? k4g - sg * xq : 0;
-            if (xrow4 && ctx < CH) {
+            const bool in = mbase + xctx[i] < a.M;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * k4 + e < job.d_in) xT[(sg * job.d_in + 4 * k4 + e) * CS + ctx] = px[i][e];
-            }
+            for (int e = 0; e < 4; ++e)
+                if (e < xne[i]) xT[xdst[i] + e * CS] = in ? px[i][e] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int idx = tid + i * NT;
-            const int ctx = idx / (4 * job.nseg), rem = idx - ctx * 4 * job.nseg;
-            const int sg = rem >> 2, o4 = rem & 3;
-            if (ctx < CH) {
+            if (dctx[i] >= 0) {
+                const bool in = mbase + dctx[i] < a.M;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    dT[(sg * 16 + 4 * o4 + e) * CS + ctx] = (4 * o4 + e < job.seg[sg].count) ? pd[i][e] : 0.f;
+                for (int e = 0; e < 4; ++e) dT[ddst[i] + e * CS] = (in && e < dne[i]) ? pd[i][e] : 0.f;
             }
         }
     };
@@ -865,52 +923,95 @@ cond_gw_kernel(GwArgs a) {
     const int64_t nsteps = (a.M + CH - 1) / CH;
     int64_t st = (int64_t)split * a.spp;
     const int64_t st_end = (st + a.spp) < nsteps ? (st + a.spp) : nsteps;
-    const int64_t st_first = st;
-    if (st < st_end) {
+    if (st < st_end) {  // step 0 into buffer 0
         fetch(st * CH);
-        fetch_h(st, 0);
+        fetch_h(st, hB0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        commit(0, st * CH);
     }
-    for (; st < st_end; ++st) {
-        const int cur = (int)((st - st_first) & 1);
-        __syncthreads();  // everyone is done with the previous step; its vmcnt(0) also retires h of this step
-        commit();
-        if (st + 1 < st_end) fetch_h(st + 1, cur ^ 1);  // the other slot was last read two barriers ago
-        // raw barrier: a __syncthreads() here would wait (vmcnt(0)) for the copy just requested
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (st + 1 < st_end) fetch((st + 1) * CH);  // in flight during the MFMAs below
-        const u4* hcur = hB + cur * HB_U4;
-#pragma unroll
-        for (int sub = 0; sub < CH / 32; ++sub) {
+    __syncthreads();
+    auto step = [&](auto slot) {
+        constexpr int cur = decltype(slot)::value;
+        // here buffer `cur` and h slot `cur` are complete and visible, and nobody reads the other ones any more
+        if (st + 1 < st_end) {  // both in flight during the MFMAs below
+            fetch((st + 1) * CH);
+            fetch_h(st + 1, cur ? hB0 : hB1);
+        }
+        const float* xT = xT2 + cur * XTF;
+        const float* dT = dT2 + cur * DTF;
+        const unsigned hbase = (unsigned)(uintptr_t)(lds_void*)((cur ? hB1 : hB0) + lane);
+        static_for<0, CH / 32>([&](auto sub_c) {
+            constexpr int sub = decltype(sub_c)::value;
             const int co = 32 * sub + 8 * q;
             h8 Bh[JT], Bl[JT];
+            static_for<0, JT>([&](auto jt_c) {
+                constexpr int jt = decltype(jt_c)::value;
+#if TNF_GW_ABL == 4  // timing experiment: no B-operand reads
+                Bh[jt] = Bl[jt] = __builtin_bit_cast(h8, (u4){(unsigned)lane, (unsigned)st, (unsigned)sub, (unsigned)jt});
+#else
+                // read by hand: hipcc orders a visible LDS read of this array behind every LDS-DMA copy in flight
+                // (s_waitcnt vmcnt(0), i.e. behind the x / delta rows just requested as well); the copy in flight targets the
+                // OTHER slot, this one was completed before the barrier that ended the previous step
+                Bh[jt] = lds_read16_blind<((sub * JT + jt) * 2 + 0) * 1024>(hbase);
+                Bl[jt] = lds_read16_blind<((sub * JT + jt) * 2 + 1) * 1024>(hbase);
+#endif
+            });
+#if TNF_GW_ABL != 4
+            if constexpr (JT == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bh[0]), "+v"(Bh[1]), "+v"(Bh[2]), "+v"(Bh[3]), "+v"(Bl[0]), "+v"(Bl[1]),
+                             "+v"(Bl[2]), "+v"(Bl[3]));
+            else {
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                Bh[jt] = __builtin_bit_cast(h8, hcur[((sub * JT + jt) * 2 + 0) * 64 + lane]);
-                Bl[jt] = __builtin_bit_cast(h8, hcur[((sub * JT + jt) * 2 + 1) * 64 + lane]);
+                for (int jt = 0; jt < JT; ++jt) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Bh[jt]), "+v"(Bl[jt]));
             }
+#endif
 #pragma unroll
             for (int i = 0; i < IPW; ++i) {
                 if (wave + i * NW < items) {  // wave-uniform
+                    h8 ah, al;
+#if TNF_GW_ABL == 2  // timing experiment: no A-operand build (LDS reads, products, split)
+                    ah = al = __builtin_bit_cast(h8, (u4){(unsigned)lane, (unsigned)st, (unsigned)sub, (unsigned)i});
+#else
                     const float* dr = dT + (iseg[i] * 16 + r) * CS + co;
                     const float* xr = xT + irow[i] * CS + co;
                     const f4 a0 = *reinterpret_cast<const f4*>(xr) * *reinterpret_cast<const f4*>(dr);
                     const f4 a1 = *reinterpret_cast<const f4*>(xr + 4) * *reinterpret_cast<const f4*>(dr + 4);
                     gb[i] += (a0[0] + a0[1]) + (a0[2] + a0[3]) + (a1[0] + a1[1]) + (a1[2] + a1[3]);
-                    h8 ah, al;
 #if TNF_COND_ABLATE == 4  // timing experiment: no operand split
                     ah = al = __builtin_bit_cast(h8, (u4){__float_as_uint(a0[0]), __float_as_uint(a0[1]), __float_as_uint(a1[0]), __float_as_uint(a1[1])});
 #else
                     csplit8(a0, a1, ah, al);
 #endif
+#endif
+#if TNF_GW_ABL == 1  // timing experiment: no MFMAs
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const f4 ha = __builtin_bit_cast(f4, ah), la = __builtin_bit_cast(f4, al);
+                        const f4 hb = __builtin_bit_cast(f4, Bh[jt]), lb = __builtin_bit_cast(f4, Bl[jt]);
+                        acc[i][jt] += ha * hb + la * lb;
+                    }
+#else
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt) {
                         acc[i][jt] = cmfma32h(ah, Bh[jt], acc[i][jt]);
                         acc[i][jt] = cmfma32h(al, Bh[jt], acc[i][jt]);
                         acc[i][jt] = cmfma32h(ah, Bl[jt], acc[i][jt]);
                     }
+#endif
                 }
             }
+        });
+        if (st + 1 < st_end) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rows fetched above, and this wave's share of the h copy
+            commit(cur ^ 1, (st + 1) * CH);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    while (st < st_end) {
+        step(std::integral_constant<int, 0>());
+        if (++st >= st_end) break;
+        step(std::integral_constant<int, 1>());
+        ++st;
     }
     const float ig = 1.f / cond_gscale(*a.gmaxbits);  // the deltas were computed on scaled upstream gradients
     // ---- merge: rows of the accumulators = outputs 4q + jj, columns = hidden unit 16 jt + r ----
@@ -997,8 +1098,8 @@ static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) 
     else rc = launch_bwd_variant<DT, KS, 1, 4, true>(a, st);
     if (rc) return rc;
     const CondCfg& c = g.cfg;
-    const int jobs = c.S * (2 * (2 + (c.L - 1) + c.HT) + 2);  // gw_job(): layer-0 nets apart, the rest merged
-    const int64_t nsteps = (a.M + (KS == 4 ? 63 : 127)) / (KS == 4 ? 64 : 128);
+    const int jobs = c.S * gw_jobs_per_stage(c);  // gw_job(): layer-0 nets apart, the rest merged
+    const int64_t nsteps = (a.M + gw_ch<KS>() - 1) / gw_ch<KS>();
     // context slices of ~1 MB of h rows (32 steps), at least 8 (one per XCD) when there is enough work
     int64_t spp = 32;
     while (spp > 1 && (nsteps + spp - 1) / spp < 16) spp >>= 1;
@@ -1015,7 +1116,7 @@ static int launch_bwd_dk(const CondBwdArgs& a, const GwArgs& g, hipStream_t st) 
                            const_cast<u4*>(g.himg));
     }
     if (split * jobs > 0x7fffffff) return fail(TNF_EUNSUPPORTED, "cond_gw: grid too large");
-    hipLaunchKernelGGL((cond_gw_kernel<DT, KS, 8>), dim3((unsigned)(split * jobs)), dim3(512), 0, st, gg);
+    hipLaunchKernelGGL((cond_gw_kernel<DT, KS, kGwNW>), dim3((unsigned)(split * jobs)), dim3(64 * kGwNW), 0, st, gg);
     return check_launch("cond_gw");
 }
 
