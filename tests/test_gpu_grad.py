@@ -894,7 +894,7 @@ def test_maf_wide_backward_mfma(tnf, oracle, D, L, U, M, N):
     # measured 5.5e-6 / 7.6e-7 (bars 4 x).  The 5.5e-6 is the L = 3 case: with these 0.05-scale weights the third hidden
     # layer's tanh outputs are ~0.01, and the matrix-pipe kernels carry h as 1 - 2 r with r = sigmoid near 0.5, i.e. with an
     # ABSOLUTE quantisation of 1.2e-7 -- 1e-5 of such an h, hence of the output layer's weight gradient (h x delta); blocks
-    # fed by O(1) activations sit at 2e-7 .. 3e-7 like the generic kernel (scratch/mafwide_dbg.py prints the per-layer split)
+    # fed by O(1) activations sit at 2e-7 .. 3e-7 like the generic kernel (tools/mafwide_dbg.py prints the per-layer split)
     grad_err("MAF wide MFMA backward vs the generic kernel: d params", res[0][0], res[1][0], 2.2e-5)
     grad_err("MAF wide MFMA backward vs the generic kernel: d z", res[0][1], res[1][1], 3e-6)
     mflat = torch.cat([torch.tensor(np.concatenate([Mk.reshape(-1), Mk.reshape(-1)])) for Mk in Ms])

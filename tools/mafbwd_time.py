@@ -1,0 +1,22 @@
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch_nf_amd as tnf
+for D, U, N in ((64, 64, 1 << 18), (32, 32, 1 << 18), (48, 64, 1 << 18), (6, 20, 1 << 18)):
+    np.random.seed(0)
+    layer = tnf.MAF(D, 2, U)
+    rng = np.random.RandomState(0)
+    p = torch.tensor(rng.normal(0, 0.1, (1, layer.count_num_params()))).float().cuda().requires_grad_()
+    z = torch.randn(1, N, D, device="cuda")
+    def fwd():
+        with torch.no_grad():
+            layer.inverse_and_log_det(z, p)
+    def step():
+        p.grad = None
+        zo, ld = layer.inverse_and_log_det(z, p)
+        (zo.sum() + ld.sum()).backward()
+    for fn, name in ((fwd, "inverse"), (step, "inv+bwd")):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        print("MAF D=%d U=%d N=%d %-8s %8.3f ms  %8.1f M samples/s" % (D, U, N, name, dt * 1e3, N / dt / 1e6), flush=True)
