@@ -34,7 +34,9 @@ print("RES %%.5f %%.5f %%.6e" %% (np.median(ms), ms.min(), float(lp.double().sum
 for r in range(rounds):
     for n in names:
         env = dict(os.environ)
-        if n.startswith("fv"):
+        if n == "base":
+            pass
+        elif n.startswith("fv"):
             env["TNF_FLOW_VARIANT"] = n[2:]
         else:
             env["TNF_LIB_PATH"] = os.path.join(ROOT, "scratch", "abl2", "lib%s.so" % n)

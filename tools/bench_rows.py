@@ -88,7 +88,8 @@ def widened_rows(tnf):
                                  "[64,64]: last Linear fused into the flow kernel, params (M, 20464) never materialised"}
     t = timeit(train, 3)
     res["cond_flow_train_step"] = {"contexts": M, "ms": round(t * 1e3, 3), "value": round(M / t / 1e6, 2),
-                                   "unit": "M contexts/s", "what": "forward + backward through param_net (fused pair)"}
+                                   "unit": "M contexts/s", "what": "forward + backward through param_net (fused pair; hidden weight "
+                                   "gradients of param_net as split-K products)"}
     del x, z, cde, nf
     nf = tnf.NormFlow(16, False, "AR", 1, 2, 32)
     z = torch.randn(1, 1 << 20, 16, device="cuda")
@@ -138,4 +139,23 @@ def widened_rows(tnf):
     res["forward_train_step"] = {"samples": 1 << 19, "ms": round(t * 1e3, 3), "value": round((1 << 19) / t / 1e6, 1),
                                  "unit": "M samples/s", "what": "z, log_q = nf(N) with fresh batch statistics, D=64 S=4; "
                                  "backward through the batch moments (one autograd node, tnf_flow_forward_train_*)"}
+    del nfe, om
+    # flows wider than the one-kernel shapes (num_units = 64; MAF at D = 64): per-layer kernels, two-pass MFMA backward
+    for key, arch, stages in (("wide_flow_train_step", "coupling", 4), ("wide_ar_flow_train_step", "AR", 2)):
+        np.random.seed(0)
+        nfw = tnf.NormFlow(64, False, arch, stages, 2, 64)
+        zw = torch.randn(1, 1 << 18, 64, device="cuda")
+        with torch.no_grad():
+            nfw(4096)
+
+        def wide():
+            nfw.params.grad = None
+            (-nfw.log_prob(zw).mean()).backward()
+
+        t = timeit(wide, 3)
+        res[key] = {"samples": 1 << 18, "ms": round(t * 1e3, 3), "value": round((1 << 18) / t / 1e6, 1), "unit": "M samples/s",
+                    "what": "NormFlow(64, False, %r, %d, 2, num_units=64): -mean(log_prob) forward + backward; wide "
+                            "fp32-MFMA layer kernels, backward = records -> sample-contracting GEMM -> ordered reduce "
+                            "(coupling_wide_bwd.hip)" % (arch, stages)}
+        del nfw, zw
     return res
