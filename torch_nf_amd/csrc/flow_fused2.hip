@@ -36,6 +36,9 @@
 #ifndef TNF2_RANGE_SWZ
 #define TNF2_RANGE_SWZ 1  // XOR-swizzle the staging area (conflict-free fragment reads)
 #endif
+#ifndef TNF2_RANGE_DMA
+#define TNF2_RANGE_DMA 0  // 1: D = 64 rows enter the staging area by LDS-DMA, two slots per wave (measured: no gain)
+#endif
 #ifndef TNF2_RANGE_NTMEM
 #define TNF2_RANGE_NTMEM 2  // bit 0: non-temporal loads, bit 1: non-temporal stores of the layer-range kernel's rows.
                             // Measured on the 8-launch chain at D = 64: plain 0.820 ms, nt stores 0.742, nt loads 0.909,
@@ -386,7 +389,7 @@ flow_fused2_kernel(Flow2Args a) {
                 // rows leave through a wave-private swizzled staging tile, 1 KB (whole 128-B lines) per instruction and
                 // around the caches: straight from the fragment layout (64 B per lane group) the stores cost the kernel
                 // 0.036 ms at D = 64 (0.227 -> 0.263), this way ... (the layer-range kernel's recipe, below)
-                constexpr int CPR = D / 4, RPB = (64 / CPR) > 0 ? (64 / CPR) : 1;
+                constexpr int CPR = D / 4, RPB = (64 / D) > 0 ? (64 / D) : 1;  // rows per 256-B bank row
                 float* stg = stage + wave * 16 * D;
                 auto sw = [&](int r, int ch) -> int { return r * D + ((ch ^ ((r / RPB) & (CPR - 1))) << 2); };
 #pragma unroll
@@ -423,6 +426,8 @@ flow_fused2_kernel(Flow2Args a) {
 // the fold is owed to it and paid by the next launch, whose first layer transforms exactly that half (foldprev of
 // build_image2).  So an in-place middle launch reads 2 halves and writes 1: 392 B per sample instead of 520 at D = 64.
 // ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void2;
+
 struct Range2Args {
     Flow2Args f;
     int c_hi, c_lo;       // layer range, 2S-1 >= c_hi >= c_lo >= 0
@@ -438,6 +443,9 @@ struct Range2Args {
     float* prep_out;
     int per_launch;
     int64_t prep_slot;
+    // D = 64 rows enter the staging area by LDS-DMA, two slots per wave (set by launch_range_t when the LDS has the room):
+    // two groups in flight per wave instead of one that also occupies 32 registers on its way
+    int dma = 0;
 };
 
 // floats of the LDS region a prepared prologue consists of (everything behind the staging area)
@@ -517,8 +525,9 @@ flow_range2_kernel(Range2Args ra) {
     const int c_hi = c_hi_, c_lo = c_lo_, nr = c_hi - c_lo + 1;
     const int c_top = c_hi < nl - 1 ? c_hi + 1 : c_hi;  // folds are needed for c_lo .. c_top
     const bool final_ = FWD ? c_hi == nl - 1 : c_lo == 0;
-    float* stage = lds;                                // [NWAVES][NT * 16 rows][D]: wave-private staging of the rows in flight
-    float* img = lds + NWAVES * NT * 16 * D;           // [nr] image of layer c at index c - c_lo
+    const bool dma = ra.dma != 0;                      // (uniform) two staging slots per wave, filled by LDS-DMA
+    float* stage = lds;                                // [NWAVES][1 or 2 slots][NT * 16 rows][D]: wave-private staging of the rows in flight
+    float* img = lds + (dma ? NWAVES * 2 * (NT * 16 * D + 64) : NWAVES * NT * 16 * D);  // [nr] image of layer c at index c - c_lo
     float* fold = img + nr * I::FLOATS;                // [nr + 1][A (D) | B (D)], layer c at index c - c_lo
     float* fin = fold + (nr + 1) * 2 * D;              // pending map of layer c_lo's conditioner half: [A (H) | B (H)]
     int* kap = reinterpret_cast<int*>(fin + 2 * H);    // [nr]
@@ -671,8 +680,10 @@ flow_range2_kernel(Range2Args ra) {
     constexpr int GF = NT * 16 * D;         // floats per group
     constexpr int NI = GF / 256;            // 1 KB wave instructions per group
     constexpr int CPR = D / 4;              // 16-byte pieces per row
-    constexpr int RPB = (64 / CPR) > 0 ? (64 / CPR) : 1;  // rows per 256-B bank row
-    float* stg = stage + wave * GF;
+    constexpr int RPB = (64 / D) > 0 ? (64 / D) : 1;      // rows per 256-B bank row (64 floats)
+    constexpr int SLOT = GF + 64;  // a DMA slot: the rows of a group, then their 16 NT running log-dets (padded to 256 B)
+    float* const stg0 = stage + wave * (dma ? 2 * SLOT : GF);
+    float* stg = stg0;  // the slot of the group at hand
     auto sw_off = [&](int r, int ch) -> int {  // float offset of piece ch of row r inside the staging area
 #if TNF2_RANGE_SWZ
         return r * D + ((ch ^ ((r / RPB) & (CPR - 1))) << 2);
@@ -712,6 +723,31 @@ flow_range2_kernel(Range2Args ra) {
             ldp[t] = ldi ? ldi[row] : 0.f;
         }
     };
+    // The same group by LDS-DMA: lane l of instruction k fetches the 16-byte piece that belongs at LDS offset k KB + 16 l of
+    // the swizzled staging image (the XOR is an involution, so the source piece is the swizzled one: still one 1-KB run
+    // of global memory per wave instruction) and the copy lands in `slot` without touching a register.  The log-det
+    // inputs first: the wait in front of the fragment reads allows exactly the NI copies of the NEXT group in flight.
+    auto dma_load = [&](int64_t g, float* slot) {
+        if (ldi) {  // (uniform) one 4-byte copy per lane: lane l -> row l mod (16 NT) of the group
+            int64_t row = g * (NT * 16) + (lane & (NT * 16 - 1));
+            if (row >= a.N) row = a.N - 1;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(ldi + row), (lds_void2*)(slot + GF), 4, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int off = k * 256 + lane * 4;
+            const int r = off / D, pc = (off % D) >> 2;
+#if TNF2_RANGE_SWZ
+            const int ch = pc ^ ((r / RPB) & (CPR - 1));
+#else
+            const int ch = pc;
+#endif
+            int64_t row = g * (NT * 16) + r;
+            if (row >= a.N) row = a.N - 1;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4*>(zb + row * D + (ch << 2)), (lds_void2*)(slot + k * 256), 16, 0,
+                                             (TNF2_RANGE_NTMEM & 1) ? 2 : 0);
+        }
+    };
     auto unstage = [&](const f4 (&raw)[NI], f4 (&dlo)[NT][HT], f4 (&dhi)[NT][HT]) {
         if constexpr (!STAGED) {
 #pragma unroll
@@ -723,10 +759,12 @@ flow_range2_kernel(Range2Args ra) {
                 }
             return;
         }
+        if (!dma) {
 #pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            const int off = k * 256 + lane * 4;
-            *reinterpret_cast<f4*>(stg + sw_off(off / D, (off % D) >> 2)) = raw[k];
+            for (int k = 0; k < NI; ++k) {
+                const int off = k * 256 + lane * 4;
+                *reinterpret_cast<f4*>(stg + sw_off(off / D, (off % D) >> 2)) = raw[k];
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -778,7 +816,27 @@ flow_range2_kernel(Range2Args ra) {
 
     f4 raw[NI];
     float nld[NT];
-    load_raw(grp, raw, nld);
+    // vector-memory instructions a wave issues per group BEHIND the copies of the next group (stores of rows, log-dets,
+    // log_prob): the wait in front of a group's fragment reads allows exactly these + the next group's copies in flight
+    // (vector memory retires in order, stores included), so a wave never waits for its own stores.  Exact for every group
+    // that has a successor: only the very last group of the batch can be partial, and nothing waits behind it.
+    const int n_copy = NI + (ldi ? 1 : 0);
+    const int n_store = (zo ? (((final_ || HI_LAST || ra.store_cond) && (final_ || !HI_LAST || ra.store_cond)) ? NI : NT * 16 / (64 / (H / 4))) : 0) +
+                        (sldo ? NT : 0) + (lpo ? NT : 0);
+    bool first_ = true;  // the first group has no stores of a predecessor behind its copies
+    auto wait_vm = [&](int n) {  // s_waitcnt vmcnt(n), n uniform; the immediate has 6 bits
+        switch (n < 63 ? n : 63) {
+#define TNF2_WVM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+            TNF2_WVM(0) TNF2_WVM(1) TNF2_WVM(2) TNF2_WVM(3) TNF2_WVM(4) TNF2_WVM(5) TNF2_WVM(6) TNF2_WVM(7) TNF2_WVM(8) TNF2_WVM(9)
+            TNF2_WVM(10) TNF2_WVM(11) TNF2_WVM(12) TNF2_WVM(13) TNF2_WVM(14) TNF2_WVM(15) TNF2_WVM(16) TNF2_WVM(17) TNF2_WVM(18)
+            TNF2_WVM(19) TNF2_WVM(20) TNF2_WVM(21) TNF2_WVM(22) TNF2_WVM(23) TNF2_WVM(24) TNF2_WVM(25) TNF2_WVM(26) TNF2_WVM(27)
+            TNF2_WVM(28) TNF2_WVM(29) TNF2_WVM(30) TNF2_WVM(31) TNF2_WVM(32)
+#undef TNF2_WVM
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    if (STAGED && dma) dma_load(grp, stg);
+    else load_raw(grp, raw, nld);
 
     for (;;) {
         int nxt_off = 0;
@@ -793,9 +851,18 @@ flow_range2_kernel(Range2Args ra) {
             ssup[t] = 0.f;
             ldp[t] = nld[t];
         }
+        if (STAGED && dma) {
+            // the other slot was drained (its results read back into registers) before the stores of the group before
+            // this one were issued: free for the group after this one, which so is in flight together with this one's tail
+            if (has_next) dma_load(nxt, stg == stg0 ? stg0 + SLOT : stg0);
+            wait_vm(first_ ? (has_next ? n_copy : 0) : (has_next ? n_copy + n_store : n_store));
+            first_ = false;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ldp[t] = ldi ? stg[GF + 16 * t + s] : 0.f;
+        }
         unstage(raw, lo, hi);
         enter(lo, hi, ssup);
-        if (has_next) load_raw(nxt, raw, nld);
+        if (!(STAGED && dma) && has_next) load_raw(nxt, raw, nld);
 #if TNF2_RANGE_ABL == 0  // (1, 2 = timing experiments: loads and stores only)
         layers(std::false_type{}, lo, hi, ssum);
 #endif
@@ -804,8 +871,8 @@ flow_range2_kernel(Range2Args ra) {
         for (int t = 1; t < NT; ++t) chk += ssum[t];
         if (PREC == 0 && __builtin_expect(__any(chk != chk), 0)) {  // out-of-range input: exact first-layer contractions
             {
-                f4 again[NI];  // (the prefetch of the next group stays in `raw`)
-                load_raw(grp, again, ldp);
+                f4 again[NI];  // (the prefetch of the next group stays in `raw`; with LDS-DMA this group still lies in its slot)
+                if (!(STAGED && dma)) load_raw(grp, again, ldp);
                 unstage(again, lo, hi);
             }
 #pragma unroll
@@ -932,6 +999,7 @@ flow_range2_kernel(Range2Args ra) {
         }
         if (!has_next) break;
         grp = nxt;
+        if (STAGED && dma) stg = stg == stg0 ? stg0 + SLOT : stg0;
     }
 }
 
@@ -999,9 +1067,14 @@ int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log
 
 
 template <int H, int L, int PREC, bool FWD = false>
-static int launch_range_t(const Range2Args& ra, int64_t M, hipStream_t st) {
+static int launch_range_t(const Range2Args& ra_in, int64_t M, hipStream_t st) {
     constexpr int NT = TNF2_RANGE_NT, NW = TNF2_RANGE_NW;
-    const size_t smem = (size_t)range2_lds_floats<H, L>(ra.c_hi - ra.c_lo + 1) * sizeof(float);
+    size_t smem = (size_t)range2_lds_floats<H, L>(ra_in.c_hi - ra_in.c_lo + 1) * sizeof(float);
+    Range2Args ra = ra_in;
+    constexpr bool staged = (H == 32 || TNF2_RANGE_STAGE16) && TNF2_RANGE_STAGE;
+    const size_t slot2 = ((size_t)NW * NT * 32 * H + (size_t)NW * 2 * 64) * sizeof(float);  // a second staging slot per wave + the log-det lines
+    ra.dma = (TNF2_RANGE_DMA && staged && smem + slot2 <= 160 * 1024) ? 1 : 0;
+    if (ra.dma) smem += slot2;
     const bool hf = (ra.c_hi & 1) != 0, hl = (ra.c_lo & 1) != 0;
     void (*kern)(Range2Args);
     if constexpr (FWD) {
