@@ -39,6 +39,9 @@
 #ifndef TNF2_RANGE_DMA
 #define TNF2_RANGE_DMA 0  // 1: D = 64 rows enter the staging area by LDS-DMA, two slots per wave (measured: no gain)
 #endif
+#ifndef TNF2_RANGE_ALT
+#define TNF2_RANGE_ALT 1  // odd launches of a chain sweep the rows back to front (what the launch before touched last is still on die)
+#endif
 #ifndef TNF2_RANGE_NTMEM
 #define TNF2_RANGE_NTMEM 2  // bit 0: non-temporal loads, bit 1: non-temporal stores of the layer-range kernel's rows.
                             // Measured on the 8-launch chain at D = 64: plain 0.820 ms, nt stores 0.742, nt loads 0.909,
@@ -667,8 +670,14 @@ flow_range2_kernel(Range2Args ra) {
     const int64_t per_block = (ngroups + gridDim.x - 1) / gridDim.x;
     const int64_t g_lo = (int64_t)blockIdx.x * per_block;
     const int64_t g_hi = (g_lo + per_block < ngroups) ? g_lo + per_block : ngroups;
-    int64_t grp = g_lo + wave;
-    if (grp >= g_hi) return;
+    if (g_lo + wave >= g_hi) return;
+#if TNF2_RANGE_ALT  // odd launches of a chain sweep the rows back to front: a launch starts where the one before ended
+    const bool rev_ = (launch_ix & 1) != 0;
+    auto gmap = [&](int64_t x) -> int64_t { return rev_ ? ngroups - 1 - x : x; };
+#else
+    auto gmap = [&](int64_t x) -> int64_t { return x; };
+#endif
+    int64_t grp = gmap(g_lo + wave);
 
     // ---- global <-> register traffic goes through a wave-private LDS staging area in WHOLE 1 KB pieces ----
     // The MFMA lane mapping wants lane (s, q) to hold 16 bytes of row s: loaded straight from memory that is 16 rows x
@@ -841,8 +850,9 @@ flow_range2_kernel(Range2Args ra) {
     for (;;) {
         int nxt_off = 0;
         if (lane == 0) nxt_off = atomicAdd(qhead, 1);
-        const int64_t nxt = g_lo + __builtin_amdgcn_readfirstlane(nxt_off);
-        const bool has_next = nxt < g_hi;
+        const int64_t nxt_q = g_lo + __builtin_amdgcn_readfirstlane(nxt_off);
+        const bool has_next = nxt_q < g_hi;
+        const int64_t nxt = gmap(nxt_q);
         f4 lo[NT][HT], hi[NT][HT];
         float ssum[NT], ssup[NT], ldp[NT];
 #pragma unroll
