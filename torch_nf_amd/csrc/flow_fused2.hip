@@ -15,6 +15,9 @@
 #ifndef TNF2_NW
 #define TNF2_NW 8   // waves per workgroup (one workgroup per CU: the operand images take most of the LDS)
 #endif
+#ifndef TNF2_NW16
+#define TNF2_NW16 12  // ... at D = 32: the tile state is half as wide, three waves per SIMD fit their registers (0.1746 -> 0.1686 ms; 16: 0.182)
+#endif
 #ifndef TNF2_RANGE_NT
 #define TNF2_RANGE_NT 2   // the layer-range kernel's tiles per wave iteration / waves per workgroup / workgroups per CU
 #endif
@@ -1050,10 +1053,11 @@ static int launch2_t(const Flow2Args& a, int64_t M, hipStream_t st) {
 template <int H, int L>
 static int launch2_v(const Flow2Args& a, int64_t M, int forward, hipStream_t st) {
     // the reference's usual depth (num_stages = 4): layer loop fully unrolled
+    constexpr int NW = H == 16 ? TNF2_NW16 : TNF2_NW;
 #if TNF2_UNROLL
-    if (a.S == 4) return forward ? launch2_t<H, L, TNF2_NT, TNF2_NW, 4, true>(a, M, st) : launch2_t<H, L, TNF2_NT, TNF2_NW, 4, false>(a, M, st);
+    if (a.S == 4) return forward ? launch2_t<H, L, TNF2_NT, NW, 4, true>(a, M, st) : launch2_t<H, L, TNF2_NT, NW, 4, false>(a, M, st);
 #endif
-    return forward ? launch2_t<H, L, TNF2_NT, TNF2_NW, 0, true>(a, M, st) : launch2_t<H, L, TNF2_NT, TNF2_NW, 0, false>(a, M, st);
+    return forward ? launch2_t<H, L, TNF2_NT, NW, 0, true>(a, M, st) : launch2_t<H, L, TNF2_NT, NW, 0, false>(a, M, st);
 }
 
 int launch_flow_fused2(const float* z, float* z0, float* sum_log_det, float* log_prob, int64_t Mz, int64_t Mp, int64_t N,
