@@ -37,7 +37,7 @@ class _SplitKLinear(torch.autograd.Function):
         M = x.size(0)
         B = _SplitKLinear.BLOCKS
         rows = (M // B) * B
-        g_w = torch.bmm(g[:rows].view(B, M // B, -1).transpose(1, 2), x[:rows].view(B, M // B, -1)).sum(0)
+        g_w = torch.bmm(g[:rows].view(B, M // B, -1).transpose(1, 2), x[:rows].reshape(B, M // B, -1)).sum(0)
         if rows < M:
             g_w = g_w + g[rows:].t() @ x[rows:]
         g_x = g @ weight if ctx.needs_input_grad[0] else None
