@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_source_hash  # noqa: E402
 
-KEEP = ("flow_fused", "flow_range", "flow_bwd", "coupling_mfma", "coupling_bwd", "cond_flow", "cond_gw", "maf_", "to_interval")
+KEEP = ("flow_fused", "flow_range", "flow_bwd", "coupling_mfma", "coupling_bwd", "coupling_wide", "wide_gw", "backward_reduce", "cond_flow", "cond_gw",
+        "cond_gh", "maf_", "to_interval")
 
 
 def base(name):
